@@ -1,0 +1,216 @@
+/*
+ * volviz.h -- C-ABI boundary of the MI355X-native volume ray-marcher.
+ *
+ * This header is what a host application (the reference's glwidget.cpp /
+ * slicewidget.cpp, or any FFI) binds instead of the reference's kernel.cuh.
+ * Every entry point cites the reference interface it replaces.  All types are
+ * plain C: pointers, sizes, PODs.  No torch / HIP types appear in signatures
+ * (a stream is passed as an opaque void* that is a hipStream_t; NULL = the
+ * default stream).
+ *
+ * Conventions
+ *   - every function returns VV_OK (0) or a negative vv_status; it never calls
+ *     exit() (the reference's checkCudaErrors does: include/helper_cuda.h:763-777);
+ *     vv_last_error() returns the text for the last failure on the context.
+ *   - calls are synchronous from the caller's view unless a stream is passed
+ *     AND the output buffer is device memory, in which case the work is only
+ *     enqueued on that stream (reference contract: kernel.cu:452,517 fence each call).
+ *   - a context owns one volume, one transfer function, scratch buffers
+ *     (reference: file-static globals, kernel.cu:35-51).  Not re-entrant.
+ *   - volume layout: u8 or f32, x fastest, then y, then z (kernel.cu:477,
+ *     volumegenerator.cpp:41).
+ *   - output image: RGBA u8, row-major, row 0 = bottom (GL), W*H*4 bytes
+ *     (glwidget.cpp:365-369, kernel.cu:365).
+ */
+#ifndef VOLVIZ_H
+#define VOLVIZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- reference PODs, byte-identical to kernel.cuh:18-40 ------------------- */
+#ifndef SLICE_NONE
+#define SLICE_NONE      -1   /* kernel.cuh:18 */
+#define SLICE_PLANE      0   /* kernel.cuh:19 */
+#define SLICE_PLANE_CUT  1   /* kernel.cuh:20 */
+#endif
+#ifndef TRANSFER_PRESET_DEFAULT
+#define TRANSFER_PRESET_DEFAULT -1  /* kernel.cuh:22 */
+#define TRANSFER_PRESET_ENGINE   0  /* kernel.cuh:23 */
+#define TRANSFER_PRESET_MRI      1  /* kernel.cuh:24 */
+#endif
+
+struct slice_params {        /* kernel.cuh:26-29 */
+    int   type;              /* SLICE_NONE / SLICE_PLANE / SLICE_PLANE_CUT */
+    float params[6];         /* plane point xyz, plane normal xyz (cube space) */
+};
+
+struct camera_params {       /* kernel.cuh:31-35 */
+    float origin[3];         /* world-space eye (glwidget.cpp:271-273) */
+    float fovX, fovY;        /* degrees; fovX = fovY*aspect (glwidget.cpp:340-341) */
+    float scale[3];          /* object scale (glwidget.cpp:267-269) */
+};
+
+struct shading_params {      /* kernel.cuh:37-40 */
+    int  transferPreset;     /* carried, never read by the kernel (as in the reference) */
+    bool phongShading;
+};
+
+/* params.h:46 canonicalOrientation, same enumerator values */
+typedef enum {
+    VV_HORIZONTAL = 0, VV_SAGITTAL = 1, VV_CORONAL = 2,
+    VV_N_CANONICAL_ORIENTATIONS = 3, VV_FREE_FORM = 4
+} vv_orientation;
+
+/* ---- status ----------------------------------------------------------------- */
+typedef enum {
+    VV_OK = 0,
+    VV_ERR_INVALID = -1,     /* bad argument */
+    VV_ERR_NO_VOLUME = -2,   /* render/slice before a volume was loaded */
+    VV_ERR_DEVICE = -3,      /* HIP runtime error */
+    VV_ERR_NOMEM = -4,
+    VV_ERR_IO = -5
+} vv_status;
+
+typedef struct vv_context vv_context;
+
+typedef enum { VV_VOXEL_U8 = 0, VV_VOXEL_F32 = 1 } vv_voxel_type;
+
+/* Trilinear reconstruction model (what tex3D does in kernel.cu:102,589,628).
+ *   VV_FILTER_TEX8  : CUDA texture-unit model -- interpolation weights rounded
+ *                     to 8 fractional bits (1.8 fixed point).  Default.
+ *   VV_FILTER_EXACT : full float weights.                                     */
+typedef enum { VV_FILTER_TEX8 = 0, VV_FILTER_EXACT = 1 } vv_filter;
+
+/* Early-ray termination.
+ *   VV_ERT_REFERENCE : the reference's behaviour -- `break` leaves only the
+ *                      30-sample inner loop (kernel.cu:272-274); every later
+ *                      chunk still composites its first sample.  Default.
+ *   VV_ERT_TRUE      : the ray stops for good once alpha > threshold.          */
+typedef enum { VV_ERT_REFERENCE = 0, VV_ERT_TRUE = 1 } vv_ert_mode;
+
+/* Where front/back ray end points come from (first-pass contract,
+ * firstpass.vert:6, glwidget.cpp:198-228).                                    */
+typedef enum {
+    VV_RAYS_IMAGES = 0,   /* two RGBA8 images = the reference's FBO0/FBO1        */
+    VV_RAYS_ANALYTIC = 1  /* ray/box intersection computed from the camera       */
+} vv_ray_mode;
+
+typedef struct vv_ray_source {
+    int            mode;             /* vv_ray_mode */
+    /* VV_RAYS_IMAGES: RGBA8, row 0 = bottom, sampled at (x/W, y/H) with point
+     * filtering exactly like tex2D(inTexture0, ..) in kernel.cu:317-318.      */
+    const uint8_t *front;            /* img_w*img_h*4 bytes */
+    const uint8_t *back;
+    int            img_w, img_h;     /* FBO size (reference: widget size = 3x the render size) */
+    int            images_on_device; /* 0 = host pointers, 1 = device pointers */
+    /* VV_RAYS_ANALYTIC: camera basis (camera.cpp:78-91); eye = camera_params.origin,
+     * projection = perspective(fovY, aspect) as glwidget.cpp:338.             */
+    float          look[3];
+    float          up[3];
+    float          aspect;           /* <= 0 : use W/H */
+    int            quantize8;        /* 1 = round end points to RGBA8 like the FBO does */
+} vv_ray_source;
+
+typedef struct vv_render_options {
+    float    step[3];        /* per-axis step; all 0 => 1/dims (kernel.cu:415)   */
+    float    ert_threshold;  /* 0 => .95f (kernel.cu:272)                        */
+    int      filter;         /* vv_filter                                        */
+    int      ert_mode;       /* vv_ert_mode                                      */
+    int      slab_row_begin; /* render only 14-pixel slab rows [begin,end) of    */
+    int      slab_row_end;   /* the global slab grid; 0,0 => all (multi-GPU shard)*/
+    int      count_samples;  /* 1 => count executed samples (vv_last_sample_count)*/
+    uint32_t *touched_bricks;/* device bitmap, 1 bit per 8^3 brick, or NULL:     */
+                             /* instrumentation for the roofline's byte model    */
+} vv_render_options;
+
+/* ---- lifecycle ---------------------------------------------------------------- */
+/* replaces initCuda() (kernel.cuh:44, kernel.cu:369-373).  device < 0 => current device. */
+int  vv_init(int device, vv_context **out_ctx);
+int  vv_shutdown(vv_context *ctx);
+const char *vv_last_error(const vv_context *ctx);   /* ctx may be NULL (global error) */
+
+/* ---- volume + transfer function: replaces cudaLoadVolume (kernel.cuh:53, kernel.cu:456-498).
+ * texels: host pointer, nx*ny*nz voxels, x fastest.  tf: 256 RGBA float entries.
+ * Reloading frees the previous volume (the reference leaks it).                 */
+int  vv_load_volume_u8 (vv_context *ctx, const uint8_t *texels, size_t size,
+                        int nx, int ny, int nz, const float tf[1024]);
+int  vv_load_volume_f32(vv_context *ctx, const float *texels, size_t size,
+                        int nx, int ny, int nz, const float tf[1024]);
+/* Same, from a buffer already resident in HBM (e.g. written by vv_generate_*). */
+int  vv_load_volume_device(vv_context *ctx, const void *dev_texels, int voxel_type,
+                           int nx, int ny, int nz, const float tf[1024], void *stream);
+int  vv_set_transfer_function(vv_context *ctx, const float tf[1024]);
+
+/* ---- ray march: replaces runCuda (kernel.cuh:46-51, kernel.cu:388-453) ----------
+ * rgba_out: W*H*4 bytes; out_on_device selects host or device pointer.
+ * Pixels the reference never writes (column W-1, row H-1) are left untouched.   */
+int  vv_render(vv_context *ctx, int width, int height,
+               const struct slice_params *slice,
+               const struct camera_params *camera,
+               const struct shading_params *shading,
+               const vv_ray_source *rays,
+               const vv_render_options *opts,     /* NULL => reference defaults */
+               uint8_t *rgba_out, int out_on_device, void *stream);
+
+/* ---- slice view: replaces invoke_slice_kernel (kernel.cuh:59, kernel.cu:506-519)
+ * and invoke_advanced_slice_kernel (kernel.cuh:61, kernel.cu:522-541).
+ * buffer: height*width floats; element (j,i) is stored at j*height+i exactly as
+ * the reference does (kernel.cu:550,604).  legacy != 0 selects the 4-argument
+ * slicekernel.cu:51-82 semantics (sagittal only, no scale, no bounds check).   */
+int  vv_slice(vv_context *ctx, float *buffer, size_t height, size_t width,
+              float dx, float dy, float dz, int orientation,
+              const float scale[3], int legacy, int filter,
+              int out_on_device, void *stream);
+int  vv_slice_advanced(vv_context *ctx, float *buffer, size_t height, size_t width,
+                       const float trans[16] /* row-major, CS123Algebra.h:278-281 */,
+                       const float scale[3], int filter,
+                       int out_on_device, void *stream);
+
+/* Slice transform of the free-form slice view: SliceWidget::getTransformationMatrix
+ * (slicewidget.cpp:147-165) = T(+.5) T(dx,dy,dz) Rx(theta) Ry(phi) Rz(psi) T(-.5),
+ * binary32, row-major, multiplied left to right (cs123math/CS123Matrix.cpp:27-62).
+ * Angles must lie in [-3.2, 3.2) (the reference asserts this).  Host-only.       */
+int  vv_slice_matrix(float dx, float dy, float dz, float theta, float phi, float psi,
+                     float out[16]);
+
+/* ---- procedural generator: replaces VolumeGenerator::drawEllipsoid / drawDefaultBrain
+ * (volumegenerator.cpp:31-119).  One fused pass applies the n ellipsoids in order
+ * to a zero-filled volume, bit-identical to n successive drawEllipsoid calls.
+ * out: nx*ny*nz bytes (host or device).                                          */
+int  vv_generate_ellipsoids(vv_context *ctx, uint8_t *out, int out_on_device,
+                            int nx, int ny, int nz, int n,
+                            const float *centers /* n*3 */, const float *axes /* n*3 */,
+                            const uint8_t *colors /* n */, void *stream);
+int  vv_generate_default_brain(vv_context *ctx, uint8_t *out, int out_on_device,
+                               int nx, int ny, int nz, void *stream);
+/* u8 -> f32 promotion v/255 on the device (build extension for f32 configs). */
+int  vv_promote_u8_to_f32(vv_context *ctx, const uint8_t *dev_in, float *dev_out,
+                          size_t n, void *stream);
+/* Synthetic "noise" volume V2 of the measurement plan: smooth hash field. */
+int  vv_generate_noise_u8(vv_context *ctx, uint8_t *dev_out, int nx, int ny, int nz,
+                          uint32_t seed, void *stream);
+
+/* ---- transfer-function presets: transfer_functions.h:4-9 as closed forms -------- */
+typedef enum { VV_TF_ENGINE = 0, VV_TF_HEAD = 1, VV_TF_MRI = 2 } vv_tf_preset;
+int  vv_transfer_preset(int preset, float tf_out[1024]);
+
+/* ---- .t3d container (volumegenerator.cpp:147-220): 3 x u64 LE header + bytes ---- */
+int  vv_t3d_read_header(const char *path, int header, int *nx, int *ny, int *nz);
+int  vv_t3d_read (const char *path, int header, uint8_t *dst, size_t capacity);
+int  vv_t3d_write(const char *path, int header, const uint8_t *src, int nx, int ny, int nz);
+
+/* ---- metrics (the reference only has a clock() overlay) ---------------- */
+float              vv_last_frame_ms(const vv_context *ctx);      /* hipEvent time of the last vv_render */
+unsigned long long vv_last_sample_count(vv_context *ctx);        /* executed samples, if count_samples */
+int                vv_volume_dims(const vv_context *ctx, int dims[3], int *voxel_type);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLVIZ_H */

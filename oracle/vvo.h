@@ -1,0 +1,87 @@
+/*
+ * vvo.h -- CPU oracle: a plain-C restatement of the reference's hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (volume-viz_amd/, include/)
+ * links, loads or calls this.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may use it, and only as the checker / the CPU
+ * baseline.
+ *
+ * PARITY PINNING:
+ *   - generator (vvo_draw_ellipsoid / vvo_draw_default_brain): PINNED bit-exactly
+ *     against the reference's own volumegenerator.cpp compiled unmodified
+ *     (oracle/_ref, see oracle/Makefile) and against the tests/golden brain fixtures
+ *     that compiled reference produced.
+ *   - transfer functions: PINNED against tests/golden/tf_*.f32 (parsed from
+ *     transfer_functions.h:4-9).
+ *   - slice matrix (vvo_slice_matrix): PINNED against the compiled reference
+ *     cs123math/CS123Matrix.cpp (oracle/_ref).
+ *   - ray march + slice kernels (kernel.cu, implicit.cu): PARITY UNPINNED by the
+ *     reference -- it has no tests or golden images, and kernel.cu cannot be built
+ *     here (needs nvcc, CUDA texture references, CUDA-GL interop).  The oracle
+ *     follows the source line by line (citations at each function) and pins the
+ *     undefined / hardware-dependent behaviour as documented in DESIGN.md
+ *     ("oracle pins"); closed-form known-answer tests in tests/ check it.
+ *
+ * Arithmetic: strict IEEE binary32, no contraction (-ffp-contract=off), in the
+ * order the reference source writes it; explicit fmaf only inside the texture
+ * unit model (vvo_tex3d), which is hardware in the reference.
+ */
+#ifndef VVO_H
+#define VVO_H
+
+#include "../include/volviz.h"   /* PODs + option enums only */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vvo_volume {
+    const void *data;     /* u8 or f32, x fastest */
+    int type;             /* vv_voxel_type */
+    int nx, ny, nz;
+} vvo_volume;
+
+/* ---- generator: volumegenerator.cpp:31-119 --------------------------------- */
+void vvo_draw_ellipsoid(uint8_t *vol, int nx, int ny, int nz,
+                        const float center[3], const float axes[3], uint8_t color);
+void vvo_draw_default_brain(uint8_t *vol /* zero-filled by callee */, int nx, int ny, int nz);
+
+/* ---- transfer functions as closed forms (checked against the fixtures) ------ */
+void vvo_transfer_preset(int preset, float tf[1024]);
+
+/* ---- texture unit model: tex3D(texVolume, x,y,z) with normalised coordinates,
+ * linear filter, clamp addressing (kernel.cu:485-489) ------------------------- */
+float vvo_tex3d(const vvo_volume *v, float x, float y, float z, int filter);
+
+/* ---- slice kernels: kernel.cu:543-644, slicekernel.cu:51-82 ------------------ */
+void vvo_slice(const vvo_volume *v, float *buffer, size_t height, size_t width,
+               float dx, float dy, float dz, int orientation, const float scale[3],
+               int legacy, int filter);
+void vvo_slice_advanced(const vvo_volume *v, float *buffer, size_t height, size_t width,
+                        const float trans[16], const float scale[3], int filter);
+/* slicewidget.cpp:147-165 + cs123math/CS123Matrix.cpp:27-62 */
+void vvo_slice_matrix(float dx, float dy, float dz, float theta, float phi, float psi,
+                      float out[16]);
+
+/* ---- first pass: ray end points for pixel (x,y) of a W x H frame --------------- */
+void vvo_ray_endpoints(const vv_ray_source *rs, const struct camera_params *cam,
+                       int W, int H, int x, int y, float front[3], float back[3]);
+
+/* ---- ray march: kernel.cu:281-367 over the launch geometry of kernel.cu:415-447.
+ * Returns the number of executed samples (voxelDist <= upper iterations of the
+ * inner loop, kernel.cu:253-257) over written pixels.  threads <= 0: all cores. */
+unsigned long long vvo_render(const vvo_volume *v, const float tf[1024], int W, int H,
+                              const struct slice_params *slice,
+                              const struct camera_params *cam,
+                              const struct shading_params *shading,
+                              const vv_ray_source *rays,
+                              const vv_render_options *opts,
+                              uint8_t *rgba, int threads);
+
+/* smooth hash "noise" volume V2: reference-free synthetic input */
+void vvo_generate_noise_u8(uint8_t *out, int nx, int ny, int nz, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,326 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on the
+same inputs, and against the committed golden fixtures.
+
+Bars:
+  * generator      : bit-exact
+  * slice sampler  : bit-exact (float results, both filter modes)
+  * ray march      : RGBA8, <= 1 LSB per channel on >= 99.9 % of pixels, <= 2 LSB max
+                     (the kernel fuses multiply-adds in the per-sample position transform
+                     and uses v_rsq in Phong shading; see DESIGN.md "tolerance")
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import volviz_amd as vv
+from golden.make_fixtures import ellipsoid_cases, frame_cases, PLANE_POINT, PLANE_NORMAL
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def assert_frames_close(got, want, what=""):
+    assert got.shape == want.shape
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16)).max(axis=-1)
+    frac_gt1 = float((d > 1).mean())
+    exact = float((d == 0).mean())
+    assert d.max() <= 2, f"{what}: max diff {d.max()} LSB at {np.unravel_index(d.argmax(), d.shape)}"
+    assert frac_gt1 <= 1e-3, f"{what}: {frac_gt1:.5f} of pixels differ by more than 1 LSB"
+    return exact
+
+
+# ------------------------------------------------------------------ generator: bit-exact
+def test_generator_default_brain_fixture(ctx, golden_dir):
+    g = np.fromfile(os.path.join(golden_dir, "brain_32.u8"), np.uint8).reshape(32, 32, 32)
+    assert np.array_equal(ctx.generate_default_brain(32, 32, 32), g)
+    a = np.fromfile(os.path.join(golden_dir, "brain_aniso_20x36x52.u8"), np.uint8).reshape(52, 36, 20)
+    assert np.array_equal(ctx.generate_default_brain(20, 36, 52), a)
+
+
+@pytest.mark.parametrize("n", [64, 128, 256])
+def test_generator_hashes(ctx, golden_dir, n):
+    h = json.load(open(os.path.join(golden_dir, "generator_hashes.json")))[f"brain_{n}"]
+    assert sha(ctx.generate_default_brain(n, n, n)) == h["sha256"]
+
+
+def test_generator_random_ellipsoids(ctx, golden_dir):
+    hs = json.load(open(os.path.join(golden_dir, "generator_hashes.json")))
+    for name, dims, centers, axes, colors in ellipsoid_cases():
+        out = ctx.generate_ellipsoids(*dims, centers, axes, colors)
+        assert sha(out) == hs[name]["sha256"], name
+        assert np.array_equal(out, O.draw_ellipsoids(*dims, centers, axes, colors))
+
+
+def test_generator_edge_cases(ctx):
+    # no ellipsoid: all zero, and no marker slab (the marker is written by drawEllipsoid)
+    assert not ctx.generate_ellipsoids(17, 5, 3, np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0, np.uint8)).any()
+    for dims in ((1, 1, 1), (100, 3, 2), (15, 16, 17), (200, 1, 1)):
+        assert np.array_equal(ctx.generate_default_brain(*dims), O.draw_default_brain(*dims)), dims
+    with pytest.raises(vv.VolvizError):
+        ctx.generate_ellipsoids(8, 8, 8, np.zeros((65, 3)), np.ones((65, 3)), np.ones(65, np.uint8))
+
+
+def test_generator_large_matches_oracle_on_slabs(ctx):
+    # 512^3 on the GPU; the oracle checks it through a size-independent property: every
+    # z-slice of the N^3 brain depends only on fk = k/N, so slices at k = N/4, N/2 of the
+    # 512^3 volume equal full-oracle slices computed for those k alone.
+    n = 512
+    g = ctx.generate_default_brain(n, n, n)
+    u, c = np.unique(g, return_counts=True)
+    assert set(u.tolist()) == {0, 4, 60, 80, 100, 120}
+    assert c[u.tolist().index(4)] == n * n * len([i for i in range(n) if np.float32(i) / np.float32(n) >= 0.99])
+    # mirror symmetry is broken only by the marker slab; compare an interior slab with the oracle
+    sub = O.draw_default_brain(n, n, 1)       # k = 0 only: fk = 0
+    assert np.array_equal(g[0], sub[0])
+
+
+# ------------------------------------------------------------------ slice sampler: bit-exact
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("filt", [vv.FILTER_TEX8, vv.FILTER_EXACT])
+def test_slice_canonical_exact(ctx, dtype, filt):
+    vol = O.draw_default_brain(40, 48, 56)
+    if dtype == np.float32:
+        vol = (vol.astype(np.float32) / np.float32(255)).astype(np.float32)
+    ctx.load_volume(vol, vv.transfer_preset(vv.TF_HEAD))
+    for o in (vv.SAGITTAL, vv.HORIZONTAL, vv.CORONAL, vv.FREE_FORM):
+        for (dx, dy, dz), scale in (((0.0, 0.0, 0.0), (1, 1, 1)), ((0.05, 0.4, 0.3), (1.0, 1.0, 0.8)),
+                                    ((-0.3, 0.7, 0.5), (1.57, 1.0, 1.0))):
+            got = ctx.slice(96, 96, dx, dy, dz, o, scale, filter=filt, fill=-2.0)
+            want = O.slice(vol, 96, 96, dx, dy, dz, o, scale, filter=filt, fill=-2.0)
+            assert np.array_equal(got, want), (o, dx, dy, dz, scale)
+
+
+def test_slice_legacy_and_ragged(ctx):
+    vol = O.noise_u8(33, 17, 9, 5)
+    ctx.load_volume(vol, vv.transfer_preset(vv.TF_HEAD))
+    got = ctx.slice(64, 64, 0.1, -0.2, 0.6, legacy=True)
+    assert np.array_equal(got, O.slice(vol, 64, 64, 0.1, -0.2, 0.6, legacy=True))
+    for h, w in ((8, 4), (4, 8), (1, 1), (1, 7), (7, 1), (256, 256), (300, 1030)):
+        got = ctx.slice(h, w, 0.0, 0.5, 0.5, vv.CORONAL, fill=-1.0)
+        assert np.array_equal(got, O.slice(vol, h, w, 0.0, 0.5, 0.5, vv.CORONAL, fill=-1.0)), (h, w)
+
+
+@pytest.mark.parametrize("filt", [vv.FILTER_TEX8, vv.FILTER_EXACT])
+def test_slice_advanced_exact(ctx, filt):
+    vol = O.draw_default_brain(64, 64, 64)
+    ctx.load_volume(vol, vv.transfer_preset(vv.TF_HEAD))
+    rng = np.random.default_rng(3)
+    for _ in range(6):
+        p = [float(np.float32(v)) for v in np.concatenate([rng.uniform(-.3, .3, 3), rng.uniform(-3.1, 3.1, 3)])]
+        m = vv.slice_matrix(*p)
+        for scale in ((1, 1, 1), (1.0, 1.0, 0.8)):
+            got = ctx.slice_advanced(128, 128, m, scale, filter=filt)
+            assert np.array_equal(got, O.slice_advanced(vol, 128, 128, m, scale, filter=filt)), p
+
+
+def test_slice_goldens(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "frames_oracle.npz"))
+    ctx.load_volume(O.draw_default_brain(64, 64, 64), vv.transfer_preset(vv.TF_HEAD))
+    for oname, o in (("sagittal", vv.SAGITTAL), ("horizontal", vv.HORIZONTAL), ("coronal", vv.CORONAL)):
+        assert np.array_equal(ctx.slice(64, 64, 0.05, 0.4, 0.3, o, (1.0, 1.0, 0.8)), g[f"slice_brain64_{oname}_64"])
+    m = vv.slice_matrix(0.1, -0.05, 0.02, 0.4, -0.3, 0.2)
+    assert np.array_equal(ctx.slice_advanced(64, 64, m), g["slice_brain64_free_64"])
+
+
+# ------------------------------------------------------------------ ray march
+def test_render_golden_frames(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "frames_oracle.npz"))
+    vols = {"brain32": O.draw_default_brain(32, 32, 32), "brain64": O.draw_default_brain(64, 64, 64)}
+    tfs = {"engine": vv.TF_ENGINE, "head": vv.TF_HEAD, "mri": vv.TF_MRI}
+    worst = 1.0
+    for name, kw in frame_cases():
+        ctx.load_volume(vols[kw["vol"]], vv.transfer_preset(tfs[kw["tf"]]))
+        sp = vv.make_slice_params(kw["slice_type"], PLANE_POINT, PLANE_NORMAL)
+        img = ctx.render(kw["W"], kw["H"], vv.Camera(**kw["cam"]), slice=sp, phong=kw["phong"], fill=0x5A,
+                         options=vv.make_options(count_samples=True))
+        worst = min(worst, assert_frames_close(img, g[name], name))
+        assert ctx.last_sample_count() == int(g[name + "__samples"][0]), name
+    assert worst > 0.97
+
+
+CASES = [
+    # W, H, dims, dtype, tf, slice, phong, camera
+    (170, 170, (64, 64, 64), np.uint8, vv.TF_HEAD, vv.SLICE_NONE, False, "a"),
+    (170, 170, (64, 64, 64), np.uint8, vv.TF_ENGINE, vv.SLICE_NONE, True, "b"),
+    (200, 120, (64, 64, 64), np.float32, vv.TF_ENGINE, vv.SLICE_PLANE, False, "b"),
+    (200, 120, (48, 64, 40), np.float32, vv.TF_MRI, vv.SLICE_PLANE_CUT, True, "b"),
+    (97, 131, (40, 33, 57), np.uint8, vv.TF_ENGINE, vv.SLICE_PLANE_CUT, False, "c"),
+    (29, 43, (32, 32, 32), np.uint8, vv.TF_ENGINE, vv.SLICE_NONE, True, "a"),     # W == 1, H == 1 (mod 14)
+    (29, 43, (32, 32, 32), np.uint8, vv.TF_ENGINE, vv.SLICE_PLANE, False, "c"),
+]
+
+
+def _cam(tag, scale=(1, 1, 1)):
+    if tag == "a":
+        return vv.Camera(scale=scale)
+    if tag == "b":
+        return vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5, scale=scale)
+    return vv.Camera.orbit(3.2, 2.0, -1.1, scale=scale)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}x{c[1]}-{c[2][0]}-{np.dtype(c[3]).name}-tf{c[4]}-s{c[5]}-p{int(c[6])}-{c[7]}" for c in CASES])
+@pytest.mark.parametrize("filt", [vv.FILTER_TEX8, vv.FILTER_EXACT])
+def test_render_matches_oracle(ctx, case, filt):
+    W, H, dims, dtype, tfp, st, phong, camtag = case
+    vol = O.draw_default_brain(*dims)
+    if dtype == np.float32:
+        vol = vol.astype(np.float32) / np.float32(255)
+    tf = vv.transfer_preset(tfp)
+    ctx.load_volume(vol, tf)
+    cam = _cam(camtag)
+    sp = vv.make_slice_params(st, PLANE_POINT, PLANE_NORMAL)
+    opts = vv.make_options(filter=filt, count_samples=True)
+    got = ctx.render(W, H, cam, slice=sp, phong=phong, options=opts, fill=0xA5)
+    want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=phong, options=opts, fill=0xA5)
+    assert_frames_close(got, want)
+    assert ctx.last_sample_count() == n
+    # untouched pixels stay untouched
+    assert np.all(got[-1] == 0xA5) and np.all(got[:, -1] == 0xA5)
+
+
+def test_render_colour_tf_scale_and_step(ctx):
+    """Non-grey RGBA table, anisotropic object scale (VisMale: glwidget.cpp:686-689),
+    explicit step override (config C3 uses step = 1/512 on a 1024^3 volume)."""
+    rng = np.random.default_rng(11)
+    tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
+    tf[:, 3] *= 0.08
+    tf[:20, 3] = 0
+    vol = O.noise_u8(48, 40, 36, 0x9E3779B9)
+    ctx.load_volume(vol, tf)
+    for scale, step in (((1.57, 1.0, 1.0), None), ((1.0, 1.0, 0.8), 1 / 24), ((1, 1, 1), (1 / 96, 1 / 80, 1 / 72))):
+        cam = _cam("b", scale)
+        for ert in (vv.ERT_REFERENCE, vv.ERT_TRUE):
+            opts = vv.make_options(step=step, ert_mode=ert, count_samples=True, ert_threshold=0.8)
+            got = ctx.render(160, 90, cam, options=opts)
+            want, n = O.render(vol, tf, 160, 90, cam, options=opts)
+            assert_frames_close(got, want, f"{scale} {step} {ert}")
+            assert ctx.last_sample_count() == n
+
+
+def test_render_image_ray_source(ctx):
+    """Front/back RGBA8 images as the reference's GL first pass produces them
+    (FBO = 3x the render size, glwidget.cpp:98,291,358)."""
+    W, H = 85, 60
+    cam = _cam("b")
+    rs_hi = vv.analytic_rays(cam, quantize8=True)
+    fw, fh = 3 * W, 3 * H
+    front = np.zeros((fh, fw, 4), np.uint8); back = np.zeros((fh, fw, 4), np.uint8)
+    for y in range(fh):
+        for x in range(fw):
+            f, b = O.ray_endpoints(rs_hi, cam, fw, fh, x, y)
+            front[y, x, :3] = np.round(f * 255); back[y, x, :3] = np.round(b * 255)
+            front[y, x, 3] = back[y, x, 3] = 255
+    vol = O.draw_default_brain(32, 32, 32)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    rs = vv.image_rays(front, back)
+    for phong in (False, True):
+        got = ctx.render(W, H, cam, rays=rs, phong=phong)
+        want, _ = O.render(vol, tf, W, H, cam, rays=rs, phong=phong)
+        assert_frames_close(got, want, f"images phong={phong}")
+        assert (got[..., 3] > 0).mean() > 0.2
+
+
+def test_render_quantised_analytic(ctx):
+    vol = O.draw_default_brain(32, 32, 32)
+    tf = vv.transfer_preset(vv.TF_HEAD)
+    ctx.load_volume(vol, tf)
+    cam = _cam("c")
+    rs = vv.analytic_rays(cam, quantize8=True)
+    got = ctx.render(120, 100, cam, rays=rs)
+    want, _ = O.render(vol, tf, 120, 100, cam, rays=rs)
+    assert_frames_close(got, want)
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (1, 9), (9, 1), (2, 2), (14, 14), (15, 16), (16, 15)])
+def test_render_tiny_frames(ctx, W, H):
+    vol = O.draw_default_brain(8, 8, 8)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    for phong in (False, True):
+        got = ctx.render(W, H, vv.Camera(), phong=phong, fill=3)
+        want, _ = O.render(vol, tf, W, H, vv.Camera(), phong=phong, fill=3)
+        assert_frames_close(got, want, f"{W}x{H} phong={phong}")
+
+
+def test_render_empty_and_uniform_kat(ctx):
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(np.zeros((16, 16, 16), np.uint8), tf)
+    img = ctx.render(40, 30, vv.Camera(), fill=7)
+    assert np.all(img[:-1, :-1] == 0) and np.all(img[-1] == 7) and np.all(img[:, -1] == 7)
+    vol = np.full((16, 16, 16), 40, np.uint8)
+    ctx.load_volume(vol, tf)
+    opts = vv.make_options(ert_threshold=2.0)
+    got = ctx.render(57, 57, vv.Camera(), options=opts)
+    want, _ = O.render(vol, tf, 57, 57, vv.Camera(), options=opts)
+    assert np.array_equal(got, want)          # uniform volume: no rounding-sensitive sample exists
+
+
+def test_render_sharded_rows_reassemble(ctx):
+    """Multi-GPU sharding unit: slab-row bands rendered separately reassemble the frame."""
+    vol = O.draw_default_brain(32, 32, 32)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    cam = _cam("b")
+    for phong in (False, True):
+        full = ctx.render(60, 50, cam, phong=phong, fill=1)
+        parts = np.full_like(full, 1)
+        for rb, re in ((0, 1), (1, 3), (3, 4)):
+            ctx.render(60, 50, cam, phong=phong, options=vv.make_options(slab_rows=(rb, re)), out=parts)
+        assert np.array_equal(parts, full)
+
+
+def test_render_full_size_properties(ctx):
+    """BASELINE config C2 size (256^3 f32, 1280x720): size-independent properties instead of
+    a full oracle frame -- (1) a 3-slab-row band of the oracle matches, (2) the frame equals the
+    reassembly of its shards, (3) an empty volume renders transparent, (4) determinism."""
+    n = 256
+    vol8 = ctx.generate_default_brain(n, n, n)
+    vol = vol8.astype(np.float32) / np.float32(255)
+    tf = vv.transfer_preset(vv.TF_HEAD)
+    ctx.load_volume(vol, tf)
+    cam = vv.Camera()
+    W, H = 1280, 720
+    opts = vv.make_options(count_samples=True)
+    full = ctx.render(W, H, cam, options=opts, fill=0)
+    n_full = ctx.last_sample_count()
+    again = ctx.render(W, H, cam, options=opts, fill=0)
+    assert np.array_equal(full, again)
+    band = (25, 28)                      # slab rows through the image centre
+    want = np.zeros_like(full)
+    _, _ = O.render(vol, tf, W, H, cam, options=vv.make_options(slab_rows=band), out=want)
+    rows = slice(band[0] * 14, band[1] * 14)
+    assert_frames_close(full[rows], want[rows], "C2 band")
+    parts = np.zeros_like(full)
+    total = 0
+    nby = (H + 13) // 14
+    for rb in range(0, nby, 13):
+        ctx.render(W, H, cam, options=vv.make_options(slab_rows=(rb, min(rb + 13, nby)), count_samples=True), out=parts)
+        total += ctx.last_sample_count()
+    assert np.array_equal(parts, full) and total == n_full
+
+
+def test_errors_are_codes(ctx):
+    c2 = vv.Context(0)
+    with pytest.raises(vv.VolvizError) as e:
+        c2.render(16, 16, vv.Camera())
+    assert e.value.code == -2                       # no volume loaded
+    with pytest.raises(vv.VolvizError):
+        c2.slice(8, 8)
+    c2.load_volume(np.zeros((4, 4, 4), np.uint8), vv.transfer_preset(vv.TF_HEAD))
+    with pytest.raises(vv.VolvizError):
+        c2.render(0, 5, vv.Camera())
+    with pytest.raises(vv.VolvizError):
+        c2.render(8, 8, vv.Camera(), slice=vv.make_slice_params(5))
+    with pytest.raises(vv.VolvizError):
+        c2.render(8, 8, vv.Camera(), options=vv.make_options(step=1e-9))
+    with pytest.raises(vv.VolvizError):
+        c2.render(8, 8, vv.Camera(scale=(0, 1, 1)))
+    c2.close()

@@ -1,0 +1,102 @@
+"""CPU tests of the product's host side: the C-ABI library loads, exports every symbol
+include/volviz.h declares, and the host-only entry points agree with the golden vectors.
+No kernel is launched here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import volviz_amd as vv
+
+REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def declared_symbols():
+    h = open(os.path.join(REPO, "include", "volviz.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(vv_[a-z0-9_]+)\s*\(", h)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = vv.load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/volviz.h but not exported"
+    assert sorted(vv.EXPORTS) == syms
+
+
+def test_struct_layouts_match_kernel_cuh():
+    # kernel.cuh:26-40: 28 / 32 / 8 bytes
+    assert C.sizeof(vv.slice_params) == 28
+    assert C.sizeof(vv.camera_params) == 32
+    assert C.sizeof(vv.shading_params) == 8
+    assert vv.camera_params.fovX.offset == 12 and vv.camera_params.scale.offset == 20
+
+
+@pytest.mark.parametrize("name,preset", [("engine", vv.TF_ENGINE), ("head", vv.TF_HEAD), ("mri", vv.TF_MRI)])
+def test_transfer_presets_match_reference_tables(golden_dir, name, preset):
+    g = np.fromfile(os.path.join(golden_dir, f"tf_{name}.f32"), "<f4")
+    assert np.array_equal(vv.transfer_preset(preset), g)
+    with pytest.raises(vv.VolvizError):
+        vv.transfer_preset(17)
+
+
+def test_slice_matrix_matches_reference(golden_dir):
+    for case in json.load(open(os.path.join(golden_dir, "slice_matrices.json"))):
+        want = np.frombuffer(bytes.fromhex(case["matrix_hex"]), np.float32).reshape(4, 4)
+        assert np.array_equal(vv.slice_matrix(*case["params"]), want), case["params"]
+    with pytest.raises(vv.VolvizError):          # slicewidget.cpp:149-154 asserts the range
+        vv.slice_matrix(0, 0, 0, 3.3, 0, 0)
+
+
+def test_t3d_reads_reference_written_file(golden_dir, tmp_path):
+    lib = vv.load_library()
+    p = os.path.join(golden_dir, "brain_16.t3d").encode()
+    nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
+    assert lib.vv_t3d_read_header(p, 1, C.byref(nx), C.byref(ny), C.byref(nz)) == 0
+    assert (nx.value, ny.value, nz.value) == (16, 16, 16)
+    buf = np.zeros(16 ** 3, np.uint8)
+    assert lib.vv_t3d_read(p, 1, buf.ctypes.data, buf.size) == 0
+    import oracle_lib as O
+    assert np.array_equal(buf.reshape(16, 16, 16), O.draw_default_brain(16, 16, 16))
+    # write -> byte-identical to what the reference wrote
+    q = str(tmp_path / "out.t3d").encode()
+    assert lib.vv_t3d_write(q, 1, buf.ctypes.data, 16, 16, 16) == 0
+    assert open(q, "rb").read() == open(p, "rb").read()
+    # header-less files are 128 x 256 x 256 (volumegenerator.cpp:204-208)
+    assert lib.vv_t3d_read_header(q, 0, C.byref(nx), C.byref(ny), C.byref(nz)) == 0
+    assert (nx.value, ny.value, nz.value) == (128, 256, 256)
+    # errors are codes, never exit()
+    assert lib.vv_t3d_read(b"/nonexistent/file.t3d", 1, buf.ctypes.data, buf.size) == -5
+    assert lib.vv_t3d_read(p, 1, buf.ctypes.data, 10) == -1
+    if __import__("oracle_lib").ref() is not None:       # the reference reads back what we write
+        ref = __import__("oracle_lib").ref()
+        dims = (C.c_int * 3)()
+        out = np.zeros(16 ** 3, np.uint8)
+        assert ref.ref_load_raw(q, 1, out.ctypes.data, out.size, dims) == 16 ** 3
+        assert list(dims) == [16, 16, 16] and np.array_equal(out, buf)
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a HIP device the product must fail, not fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(vv.VolvizError) as e:
+        vv.Context(0)
+    assert e.value.code == -3
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product tree must not include / link / load anything under oracle/."""
+    for root, _, files in os.walk(os.path.join(REPO, "volume-viz_amd")):
+        if os.sep + "build" in root or os.sep + "lib" in root:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "vvo_" not in txt and "libvvoracle" not in txt and "libvvref" not in txt, os.path.join(root, f)

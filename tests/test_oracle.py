@@ -1,0 +1,221 @@
+"""CPU tests: the oracle against the reference's golden vectors and closed-form KATs."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import volviz_amd as vv
+from golden.make_fixtures import ellipsoid_cases, frame_cases, PLANE_POINT, PLANE_NORMAL
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ---------------------------------------------------------------- generator (pinned)
+def test_brain_matches_reference_fixture(golden_dir):
+    g = np.fromfile(os.path.join(golden_dir, "brain_32.u8"), np.uint8).reshape(32, 32, 32)
+    assert np.array_equal(O.draw_default_brain(32, 32, 32), g)
+    a = np.fromfile(os.path.join(golden_dir, "brain_aniso_20x36x52.u8"), np.uint8).reshape(52, 36, 20)
+    assert np.array_equal(O.draw_default_brain(20, 36, 52), a)
+
+
+@pytest.mark.parametrize("n", [32, 64, 128])
+def test_brain_hashes(golden_dir, n):
+    h = json.load(open(os.path.join(golden_dir, "generator_hashes.json")))[f"brain_{n}"]
+    b = O.draw_default_brain(n, n, n)
+    assert sha(b) == h["sha256"]
+    u, c = np.unique(b, return_counts=True)
+    assert {int(k): int(v) for k, v in zip(u, c)} == {int(k): v for k, v in h["histogram"].items()}
+
+
+def test_brain_128_histogram_matches_survey():
+    # histogram of the compiled reference at 128^3
+    b = O.draw_default_brain(128, 128, 128)
+    u, c = np.unique(b, return_counts=True)
+    assert dict(zip(u.tolist(), c.tolist())) == {0: 1535054, 4: 16384, 60: 204272, 80: 220332, 100: 100192, 120: 20918}
+
+
+def test_random_ellipsoids_hashes(golden_dir):
+    hs = json.load(open(os.path.join(golden_dir, "generator_hashes.json")))
+    for name, dims, centers, axes, colors in ellipsoid_cases():
+        out = O.draw_ellipsoids(*dims, centers, axes, colors)
+        assert sha(out) == hs[name]["sha256"], name
+
+
+@pytest.mark.skipif(O.ref() is None, reason="oracle/_ref not built (reference tree absent)")
+def test_generator_against_live_reference():
+    ref = O.ref()
+    for dims in ((48, 48, 48), (31, 17, 5), (1, 1, 1), (100, 3, 2)):
+        nx, ny, nz = dims
+        r = np.zeros((nz, ny, nx), np.uint8)
+        ref.ref_default_brain(r.ctypes.data, nx, ny, nz)
+        assert np.array_equal(O.draw_default_brain(nx, ny, nz), r), dims
+
+
+# ---------------------------------------------------------------- transfer functions (pinned)
+@pytest.mark.parametrize("name,preset", [("engine", vv.TF_ENGINE), ("head", vv.TF_HEAD), ("mri", vv.TF_MRI)])
+def test_transfer_functions(golden_dir, name, preset):
+    g = np.fromfile(os.path.join(golden_dir, f"tf_{name}.f32"), "<f4")
+    assert np.array_equal(O.transfer_preset(preset), g)
+
+
+# ---------------------------------------------------------------- slice matrix (pinned)
+def test_slice_matrices(golden_dir):
+    for case in json.load(open(os.path.join(golden_dir, "slice_matrices.json"))):
+        want = np.frombuffer(bytes.fromhex(case["matrix_hex"]), np.float32).reshape(4, 4)
+        got = O.slice_matrix(*case["params"])
+        assert np.array_equal(got, want), case["params"]
+
+
+# ---------------------------------------------------------------- texture model KATs
+def test_tex3d_voxel_centres_and_clamp():
+    rng = np.random.default_rng(0)
+    vol = rng.integers(0, 256, (5, 6, 7)).astype(np.uint8)
+    nz, ny, nx = vol.shape
+    for z in range(nz):
+        for y in range(ny):
+            for x in range(nx):
+                v = O.tex3d(vol, (x + .5) / nx, (y + .5) / ny, (z + .5) / nz)
+                assert v == np.float32(vol[z, y, x]) / np.float32(255)
+    # clamp addressing: outside half a texel from the border returns the border texel
+    assert O.tex3d(vol, 0.0, (2 + .5) / ny, (1 + .5) / nz) == np.float32(vol[1, 2, 0]) / np.float32(255)
+    assert O.tex3d(vol, 0.9999, (2 + .5) / ny, (1 + .5) / nz) == np.float32(vol[1, 2, nx - 1]) / np.float32(255)
+
+
+def test_tex3d_midpoint_and_weight_quantisation():
+    vol = np.zeros((1, 1, 2), np.float32); vol[0, 0, 1] = 1.0
+    # midway between the two texel centres: weight .5
+    assert O.tex3d(vol, 0.5, 0.5, 0.5, vv.FILTER_EXACT) == 0.5
+    # TEX8 weights live on a 1/256 lattice
+    for x in np.linspace(0.25, 0.75, 97):
+        v = O.tex3d(vol, float(np.float32(x)), 0.5, 0.5, vv.FILTER_TEX8)
+        assert abs(v * 256 - round(v * 256)) < 1e-6
+        e = O.tex3d(vol, float(np.float32(x)), 0.5, 0.5, vv.FILTER_EXACT)
+        assert abs(v - e) <= 1 / 512 + 1e-6
+
+
+def test_slice_impulse_tent():
+    # single-voxel impulse => trilinear tent footprint in the slice view (SURVEY 8c KAT)
+    n = 8
+    vol = np.zeros((n, n, n), np.float32); vol[0, 4, 4] = 1.0
+    s = O.slice(vol, 64, 64, 0, 0, 0.5 / n, vv.SAGITTAL, filter=vv.FILTER_EXACT).reshape(64, 64)
+    j, i = np.unravel_index(np.argmax(s), s.shape)
+    # peak at the voxel centre (4.5/8 => pixel 36), support of +-1 voxel (8 pixels)
+    assert (j, i) == (36, 36) and s[36, 36] == 1.0
+    assert s[36, 36 + 8] == 0 and s[36, 36 - 8] == 0 and s[36 + 4, 36] == 0.5
+    assert np.count_nonzero(s) == 15 * 15
+
+
+def test_slice_stride_quirk_and_orientations():
+    vol = O.draw_default_brain(16, 16, 16)
+    # kernel.cu:550: element (j,i) lives at j*height+i; with width < height the tail is unwritten
+    b = O.slice(vol, 8, 4, fill=-1.0)
+    assert (b.reshape(8, 4) != -1).sum() == len({j * 8 + i for j in range(8) for i in range(4) if j * 8 + i < 32})
+    for o in (vv.SAGITTAL, vv.HORIZONTAL, vv.CORONAL):
+        s = O.slice(vol, 16, 16, 0.02, 0.5, 0.5, o)
+        assert s.max() <= 1.0 and s.min() >= 0.0
+    # FREE_FORM through the canonical kernel leaves pos = offsets only (switch default)
+    s = O.slice(vol, 4, 4, 0.3, 0.5, 0.5, vv.FREE_FORM)
+    assert np.all(s == s[0])
+
+
+# ---------------------------------------------------------------- ray march KATs
+def _uniform_recurrence(tf, idx, n):
+    c, a = np.float32(tf[4 * idx]), np.float32(tf[4 * idx + 3])
+    C, A = np.float32(0), np.float32(0)
+    for _ in range(n):
+        bf = np.float32(a * np.float32(np.float32(1) - A))
+        C = np.float32(C + np.float32(c * bf)); A = np.float32(A + bf)
+    return C, A
+
+
+def test_empty_volume_is_transparent():
+    vol = np.zeros((16, 16, 16), np.uint8)
+    img, n = O.render(vol, O.transfer_preset(vv.TF_ENGINE), 40, 30, vv.Camera(), fill=7)
+    assert n > 0
+    assert np.all(img[:-1, :-1] == 0)
+    # column W-1 and row H-1 are never written (kernel.cu:297-298 slab upper bounds)
+    assert np.all(img[-1] == 7) and np.all(img[:, -1] == 7)
+
+
+def test_uniform_volume_closed_form():
+    # uniform value v, Engine TF, no Phong: every sample inside the cube composites TF[v];
+    # samples outside contribute nothing (TF[0].a == 0).  C_{k+1}=C_k+c a (1-A_k).
+    v = 40
+    vol = np.full((16, 16, 16), v, np.uint8)
+    tf = O.transfer_preset(vv.TF_ENGINE)
+    opts = vv.make_options(ert_threshold=2.0)            # no ERT
+    img, _ = O.render(vol, tf, 57, 57, vv.Camera(), options=opts)
+    hit = img[..., 3] > 0
+    assert hit.sum() > 500
+    # the centre pixel: the ray runs along z through the whole cube
+    a = np.float32(tf[4 * v + 3])
+    alphas = img[..., 3][hit].astype(int)
+    # every hit pixel must equal the recurrence for SOME sample count (it is monotone in n)
+    table = {}
+    for n in range(1, 40):
+        C, A = _uniform_recurrence(tf, v, n)
+        table[int(np.float32(min(max(A, 0), 1)) * np.float32(255))] = int(np.float32(min(max(C, 0), 1)) * np.float32(255))
+    for y, x in zip(*np.nonzero(hit)):
+        r, g, b, al = (int(t) for t in img[y, x])
+        assert r == g == b
+        assert al in table and table[al] == r, (x, y, r, al)
+    # centre ray crosses 16 voxels => about 16 in-cube samples (sphere alignment shifts by < 1)
+    _, A16 = _uniform_recurrence(tf, v, 16)
+    assert abs(int(img[28, 28, 3]) - int(A16 * 255)) <= int(a * 255) + 1
+
+
+def test_ert_reference_vs_true():
+    vol = np.full((32, 32, 32), 200, np.uint8)
+    tf = O.transfer_preset(vv.TF_ENGINE)
+    ref_img, n_ref = O.render(vol, tf, 29, 29, vv.Camera())
+    true_img, n_true = O.render(vol, tf, 29, 29, vv.Camera(), options=vv.make_options(ert_mode=vv.ERT_TRUE))
+    assert n_true < n_ref                      # the reference keeps compositing one sample per later chunk
+    d = np.abs(ref_img.astype(int) - true_img.astype(int))
+    assert d.max() <= 13                       # remaining weight < 0.05
+    assert ref_img[14, 14, 3] >= true_img[14, 14, 3] >= int(0.95 * 255)
+
+
+def test_write_ownership_when_width_is_1_mod_14():
+    # W = 29: the last block's interior threads all clamp onto pixel 27 (pin 10)
+    vol = O.draw_default_brain(16, 16, 16)
+    img, _ = O.render(vol, O.transfer_preset(vv.TF_ENGINE), 29, 15, vv.Camera(), fill=9)
+    assert np.all(img[:, 28] == 9) and np.all(img[14] == 9)
+    assert not np.any(np.all(img[:14, :28] == 9, axis=-1))
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (1, 9), (9, 1), (2, 2), (14, 14), (15, 16)])
+def test_tiny_frames_run(W, H):
+    vol = O.draw_default_brain(8, 8, 8)
+    img, _ = O.render(vol, O.transfer_preset(vv.TF_ENGINE), W, H, vv.Camera(), fill=3, phong=True)
+    assert img.shape == (H, W, 4)
+
+
+def test_slab_row_sharding_reassembles():
+    vol = O.draw_default_brain(32, 32, 32)
+    tf = O.transfer_preset(vv.TF_ENGINE)
+    cam = vv.Camera.orbit(4.0, 1.0, 0.6)
+    full, n = O.render(vol, tf, 60, 50, cam, phong=True, fill=1)
+    parts = np.full_like(full, 1)
+    total = 0
+    for rb, re in ((0, 1), (1, 3), (3, 4)):
+        _, k = O.render(vol, tf, 60, 50, cam, phong=True, options=vv.make_options(slab_rows=(rb, re)), out=parts)
+        total += k
+    assert np.array_equal(parts, full) and total == n
+
+
+def test_oracle_frames_are_stable(golden_dir):
+    """Regression pin: the oracle still produces the committed frames."""
+    g = np.load(os.path.join(golden_dir, "frames_oracle.npz"))
+    vols = {"brain32": O.draw_default_brain(32, 32, 32), "brain64": O.draw_default_brain(64, 64, 64)}
+    tfs = {"engine": vv.TF_ENGINE, "head": vv.TF_HEAD, "mri": vv.TF_MRI}
+    for name, kw in frame_cases():
+        sp = vv.make_slice_params(kw["slice_type"], PLANE_POINT, PLANE_NORMAL)
+        img, n = O.render(vols[kw["vol"]], O.transfer_preset(tfs[kw["tf"]]), kw["W"], kw["H"], vv.Camera(**kw["cam"]),
+                          slice=sp, phong=kw["phong"], fill=0x5A)
+        assert np.array_equal(img, g[name]), name
+        assert n == int(g[name + "__samples"][0]), name

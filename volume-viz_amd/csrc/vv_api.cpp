@@ -1,0 +1,458 @@
+// vv_api.cpp -- the C-ABI of include/volviz.h over the HIP kernels.
+//
+// Replaces the host half of kernel.cu (initCuda/registerCudaResources/runCuda/
+// cudaLoadVolume, kernel.cu:369-498; invoke_*_slice_kernel, kernel.cu:506-541).
+// There is no CPU fallback: every entry point that computes needs a HIP device and
+// fails with VV_ERR_DEVICE otherwise.
+#include "../../include/volviz.h"
+#include "vv_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+using namespace vv;
+
+struct vv_context {
+    int device = 0;
+    hipStream_t stream = nullptr;          // used when the caller passes no stream
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    // volume
+    void *d_vol = nullptr; size_t vol_bytes = 0; int vtype = VV_VOXEL_U8; int nx = 0, ny = 0, nz = 0;
+    // transfer function
+    float4 *d_tf = nullptr; bool tf_gray = false; bool have_tf = false;
+    // scratch
+    float *d_rad = nullptr; size_t rad_cap = 0;
+    uint8_t *d_frame = nullptr; size_t frame_cap = 0;
+    uint8_t *d_img = nullptr; size_t img_cap = 0;
+    float *d_slice = nullptr; size_t slice_cap = 0;
+    unsigned long long *d_counter = nullptr;
+    bool counter_valid = false;
+    std::string err;
+};
+
+static std::string g_err;
+
+static int fail(vv_context *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_err = msg;
+    return code;
+}
+#define HIPCHK(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail((c), VV_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+static int ensure(vv_context *c, void **p, size_t *cap, size_t need)
+{
+    if (*cap >= need && *p) return VV_OK;
+    if (*p) { HIPCHK(c, hipFree(*p)); *p = nullptr; *cap = 0; }
+    HIPCHK(c, hipMalloc(p, need));
+    *cap = need;
+    return VV_OK;
+}
+
+extern "C" {
+
+const char *vv_last_error(const vv_context *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+// ---- lifecycle: initCuda, kernel.cu:369-373 ------------------------------------
+int vv_init(int device, vv_context **out)
+{
+    if (!out) return fail(nullptr, VV_ERR_INVALID, "vv_init: out_ctx is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, VV_ERR_DEVICE, "vv_init: no HIP device available (this library has no CPU path)");
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= count) return fail(nullptr, VV_ERR_INVALID, "vv_init: device index out of range");
+    vv_context *c = new vv_context();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc((void **)&c->d_counter, sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&c->d_tf, 256 * sizeof(float4)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, VV_ERR_DEVICE, "vv_init: device set-up failed");
+    }
+    *out = c;
+    return VV_OK;
+}
+
+int vv_shutdown(vv_context *c)
+{
+    if (!c) return VV_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->d_vol) hipFree(c->d_vol);
+    if (c->d_tf) hipFree(c->d_tf);
+    if (c->d_rad) hipFree(c->d_rad);
+    if (c->d_frame) hipFree(c->d_frame);
+    if (c->d_img) hipFree(c->d_img);
+    if (c->d_slice) hipFree(c->d_slice);
+    if (c->d_counter) hipFree(c->d_counter);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return VV_OK;
+}
+
+// ---- volume + TF: cudaLoadVolume, kernel.cu:456-498 ------------------------------
+int vv_set_transfer_function(vv_context *c, const float tf[1024])
+{
+    if (!c || !tf) return fail(c, VV_ERR_INVALID, "vv_set_transfer_function: NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    bool gray = true;
+    for (int i = 0; i < 256; ++i)
+        if (!(tf[4*i] == tf[4*i+1] && tf[4*i] == tf[4*i+2])) { gray = false; break; }
+    // pageable host memory: the copy is staged before hipMemcpy returns      kernel.cu:495-496
+    HIPCHK(c, hipMemcpy(c->d_tf, tf, 1024 * sizeof(float), hipMemcpyHostToDevice));
+    c->tf_gray = gray; c->have_tf = true;
+    return VV_OK;
+}
+
+static int install_volume(vv_context *c, const void *src, bool src_on_device, int vtype,
+                          int nx, int ny, int nz, const float tf[1024], hipStream_t s)
+{
+    if (!c || !src) return fail(c, VV_ERR_INVALID, "load_volume: NULL argument");
+    if (nx < 1 || ny < 1 || nz < 1) return fail(c, VV_ERR_INVALID, "load_volume: dims must be >= 1");
+    if (vtype != VV_VOXEL_U8 && vtype != VV_VOXEL_F32) return fail(c, VV_ERR_INVALID, "load_volume: bad voxel type");
+    const size_t vsz = vtype == VV_VOXEL_F32 ? 4 : 1;
+    const size_t bytes = (size_t)nx * ny * nz * vsz;
+    if (bytes > 0xFFFFFFFFull + 1ull)
+        return fail(c, VV_ERR_INVALID, "load_volume: volumes above 4 GiB need the bricked path (not in this build)");
+    if ((size_t)nx * ny * vsz >= (1u << 24) * 1ull * 256)   // slice_bytes must stay a sane 32-bit stride
+        return fail(c, VV_ERR_INVALID, "load_volume: slice too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    // one slice + one row + 16 bytes of zero padding: weight-0 corner fetches of edge
+    // samples land here instead of needing index clamps (see vv_device.h VolumeView)
+    const size_t pad = (size_t)nx * ny * vsz + (size_t)nx * vsz + 16;
+    if (c->d_vol) { HIPCHK(c, hipFree(c->d_vol)); c->d_vol = nullptr; }   // the reference leaks here
+    HIPCHK(c, hipMalloc(&c->d_vol, bytes + pad));
+    hipStream_t st = s ? s : c->stream;
+    HIPCHK(c, hipMemsetAsync((char *)c->d_vol + bytes, 0, pad, st));
+    if (src_on_device) HIPCHK(c, hipMemcpyAsync(c->d_vol, src, bytes, hipMemcpyDeviceToDevice, st));
+    else { HIPCHK(c, hipMemcpyAsync(c->d_vol, src, bytes, hipMemcpyHostToDevice, st)); }
+    if (!src_on_device || !s) HIPCHK(c, hipStreamSynchronize(st));
+    c->vol_bytes = bytes; c->vtype = vtype; c->nx = nx; c->ny = ny; c->nz = nz;
+    if (tf) return vv_set_transfer_function(c, tf);
+    return VV_OK;
+}
+
+int vv_load_volume_u8(vv_context *c, const uint8_t *texels, size_t size, int nx, int ny, int nz, const float tf[1024])
+{
+    if (size != (size_t)nx * ny * nz) return fail(c, VV_ERR_INVALID, "vv_load_volume_u8: size != nx*ny*nz");
+    return install_volume(c, texels, false, VV_VOXEL_U8, nx, ny, nz, tf, nullptr);
+}
+int vv_load_volume_f32(vv_context *c, const float *texels, size_t size, int nx, int ny, int nz, const float tf[1024])
+{
+    if (size != (size_t)nx * ny * nz * 4) return fail(c, VV_ERR_INVALID, "vv_load_volume_f32: size != nx*ny*nz*4 bytes");
+    return install_volume(c, texels, false, VV_VOXEL_F32, nx, ny, nz, tf, nullptr);
+}
+int vv_load_volume_device(vv_context *c, const void *dev, int vtype, int nx, int ny, int nz, const float tf[1024], void *stream)
+{
+    return install_volume(c, dev, true, vtype, nx, ny, nz, tf, (hipStream_t)stream);
+}
+
+int vv_volume_dims(const vv_context *c, int dims[3], int *vtype)
+{
+    if (!c || !c->d_vol) return VV_ERR_NO_VOLUME;
+    if (dims) { dims[0] = c->nx; dims[1] = c->ny; dims[2] = c->nz; }
+    if (vtype) *vtype = c->vtype;
+    return VV_OK;
+}
+
+static VolumeView view_of(const vv_context *c)
+{
+    VolumeView V;
+    const uint32_t vsz = c->vtype == VV_VOXEL_F32 ? 4 : 1;
+    V.data = c->d_vol; V.nx = c->nx; V.ny = c->ny; V.nz = c->nz;
+    V.row_bytes = (uint32_t)c->nx * vsz;
+    V.slice_bytes = (uint32_t)c->nx * (uint32_t)c->ny * vsz;
+    return V;
+}
+
+// ---- ray march: runCuda, kernel.cu:388-453 ----------------------------------------
+static inline float vlen_h(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
+
+int vv_render(vv_context *c, int W, int H, const slice_params *slice, const camera_params *cam,
+              const shading_params *shading, const vv_ray_source *rays, const vv_render_options *opts,
+              uint8_t *rgba_out, int out_on_device, void *stream)
+{
+    if (!c) return fail(nullptr, VV_ERR_INVALID, "vv_render: NULL context");
+    if (!slice || !cam || !shading || !rays || !rgba_out) return fail(c, VV_ERR_INVALID, "vv_render: NULL argument");
+    if (W < 1 || H < 1) return fail(c, VV_ERR_INVALID, "vv_render: width/height must be >= 1");
+    if (!c->d_vol || !c->have_tf) return fail(c, VV_ERR_NO_VOLUME, "vv_render: no volume / transfer function loaded");
+    if (slice->type != SLICE_NONE && slice->type != SLICE_PLANE && slice->type != SLICE_PLANE_CUT)
+        return fail(c, VV_ERR_INVALID, "vv_render: slice type must be SLICE_NONE/PLANE/PLANE_CUT");
+    if (rays->mode == VV_RAYS_IMAGES && (!rays->front || !rays->back || rays->img_w < 1 || rays->img_h < 1))
+        return fail(c, VV_ERR_INVALID, "vv_render: image ray source needs front/back images");
+    if (rays->mode != VV_RAYS_IMAGES && rays->mode != VV_RAYS_ANALYTIC)
+        return fail(c, VV_ERR_INVALID, "vv_render: bad ray source mode");
+    for (int a = 0; a < 3; ++a)
+        if (!(cam->scale[a] > 0.f) || !std::isfinite(cam->scale[a]))
+            return fail(c, VV_ERR_INVALID, "vv_render: camera scale must be finite and > 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+
+    MarchArgs A;
+    memset(&A, 0, sizeof A);
+    FrameParams &P = A.P;
+    P.W = W; P.H = H;
+    P.nbx = W / kSlab + ((W % kSlab) ? 1 : 0);                         // kernel.cu:418-425
+    P.nby = H / kSlab + ((H % kSlab) ? 1 : 0);
+    P.conflict_x = (W >= 2 && W - 1 == (P.nbx - 1) * kSlab);
+    P.conflict_y = (H >= 2 && H - 1 == (P.nby - 1) * kSlab);
+    int rb = 0, re = P.nby;
+    P.step[0] = 1.f / (float)c->nx; P.step[1] = 1.f / (float)c->ny; P.step[2] = 1.f / (float)c->nz;   // :415
+    P.ert_thr = .95f; P.ert_true = 0;
+    A.tex8 = true; A.instr = false;
+    A.bricks = nullptr;
+    if (opts) {
+        if (opts->step[0] > 0.f || opts->step[1] > 0.f || opts->step[2] > 0.f) {
+            P.step[0] = opts->step[0]; P.step[1] = opts->step[1]; P.step[2] = opts->step[2];
+        }
+        if (opts->ert_threshold > 0.f) P.ert_thr = opts->ert_threshold;
+        P.ert_true = opts->ert_mode == VV_ERT_TRUE;
+        A.tex8 = opts->filter != VV_FILTER_EXACT;
+        if (!(opts->slab_row_begin == 0 && opts->slab_row_end == 0)) { rb = opts->slab_row_begin; re = opts->slab_row_end; }
+        A.instr = opts->count_samples != 0 || opts->touched_bricks != nullptr;
+        A.bricks = opts->touched_bricks;
+    }
+    float min_step = INFINITY;
+    for (int a = 0; a < 3; ++a) {
+        if (!(P.step[a] >= 1e-5f) || !std::isfinite(P.step[a]))
+            return fail(c, VV_ERR_INVALID, "vv_render: step must be finite and >= 1e-5 per axis");
+        min_step = fminf(min_step, P.step[a]);
+    }
+    if (rb < 0 || re > P.nby || rb > re) return fail(c, VV_ERR_INVALID, "vv_render: slab row range out of bounds");
+    // chunks needed for the longest possible ray (upper <= sqrt 3, kernel.cu:350) + slack
+    P.max_chunks = (int)(kSqrt3 / (min_step * kChunkSteps)) + 4;
+    // pixel rows owned by slab rows [rb, re) (write-ownership rule, DESIGN.md pin 10)
+    const int last_written = H >= 2 ? H - 2 : 0;
+    P.y_begin = (P.conflict_y && rb == P.nby - 1) ? H - 2 : rb * kSlab;
+    P.y_end = (re == P.nby) ? last_written + 1 : ((P.conflict_y && re == P.nby - 1) ? H - 2 : re * kSlab);
+    if (P.y_end > last_written + 1) P.y_end = last_written + 1;
+    P.slice_type = slice->type;
+    for (int a = 0; a < 3; ++a) {
+        P.slice_point[a] = slice->params[a]; P.slice_normal[a] = slice->params[3 + a];   // kernel.cu:224-225
+        P.cam_pos[a] = cam->origin[a]; P.scale[a] = cam->scale[a];
+        P.inv_scale[a] = 1.0f / cam->scale[a];
+    }
+    // kernel.cu:221-222: float * double / float -> double; tan in double; narrowed
+    P.tan_fov_x = (float)tan((double)cam->fovX * M_PI / (double)(180.f * (float)(unsigned)W));
+    P.tan_fov_y = (float)tan((double)cam->fovY * M_PI / (double)(180.f * (float)(unsigned)H));
+    P.ray_mode = rays->mode; P.quantize8 = rays->quantize8;
+    if (rays->mode == VV_RAYS_ANALYTIC) {
+        // camera.cpp:78-91 look-at basis, float
+        float lx = rays->look[0], ly = rays->look[1], lz = rays->look[2];
+        float ll = vlen_h(lx, ly, lz);
+        if (!(ll > 0.f)) return fail(c, VV_ERR_INVALID, "vv_render: look vector is zero");
+        lx /= ll; ly /= ll; lz /= ll;
+        float ux = rays->up[0], uy = rays->up[1], uz = rays->up[2];
+        float sx = ly * uz - lz * uy, sy = lz * ux - lx * uz, sz = lx * uy - ly * ux;
+        float sl = vlen_h(sx, sy, sz);
+        if (!(sl > 0.f)) return fail(c, VV_ERR_INVALID, "vv_render: up vector is parallel to look");
+        sx /= sl; sy /= sl; sz /= sl;
+        float vx = sy * lz - sz * ly, vy = sz * lx - sx * lz, vz = sx * ly - sy * lx;
+        float vl = vlen_h(vx, vy, vz);
+        vx /= vl; vy /= vl; vz /= vl;
+        P.look[0] = lx; P.look[1] = ly; P.look[2] = lz;
+        P.side[0] = sx; P.side[1] = sy; P.side[2] = sz;
+        P.up[0] = vx; P.up[1] = vy; P.up[2] = vz;
+        float aspect = rays->aspect > 0.f ? rays->aspect : (float)W / (float)H;
+        float th = (float)tan((double)cam->fovY * M_PI / 360.0);
+        P.tan_half_x = th * aspect; P.tan_half_y = th;
+    } else {
+        const size_t ib = (size_t)rays->img_w * rays->img_h * 4;
+        P.img_w = rays->img_w; P.img_h = rays->img_h;
+        if (rays->images_on_device) { P.front_img = rays->front; P.back_img = rays->back; }
+        else {
+            int rc = ensure(c, (void **)&c->d_img, &c->img_cap, 2 * ib);
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->d_img, rays->front, ib, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(c->d_img + ib, rays->back, ib, hipMemcpyHostToDevice, st));
+            P.front_img = c->d_img; P.back_img = c->d_img + ib;
+        }
+    }
+    A.V = view_of(c); A.V_type = c->vtype;
+    A.gray = c->tf_gray; A.phong = shading->phongShading;
+    A.slab_row_begin = rb; A.slab_row_end = re;
+    A.tf = c->d_tf;
+    int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));
+    if (rc) return rc;
+    A.rad = c->d_rad; A.rad_out = c->d_rad;
+    A.counter = c->d_counter;
+
+    const size_t fb = (size_t)W * H * 4;
+    uint8_t *d_out = rgba_out;
+    if (!out_on_device) {
+        rc = ensure(c, (void **)&c->d_frame, &c->frame_cap, fb);
+        if (rc) return rc;
+        d_out = c->d_frame;
+        // untouched pixels must keep the caller's bytes: stage the caller's frame first
+        HIPCHK(c, hipMemcpyAsync(d_out, rgba_out, fb, hipMemcpyHostToDevice, st));
+    }
+    A.pixels = (uint32_t *)d_out;
+    if (((uintptr_t)d_out & 3) != 0) return fail(c, VV_ERR_INVALID, "vv_render: output buffer must be 4-byte aligned");
+
+    if (A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), st));
+    c->counter_valid = A.instr;
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    if (re > rb && P.y_end > P.y_begin) {
+        if (!A.phong && W >= 2 && H >= 2) launch_rad(A, st);
+        launch_raymarch(A, st);
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    HIPCHK(c, hipGetLastError());
+    c->timed = true;
+    if (!out_on_device) {
+        HIPCHK(c, hipMemcpyAsync(rgba_out, d_out, fb, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    } else if (!stream) {
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    return VV_OK;
+}
+
+float vv_last_frame_ms(const vv_context *c)
+{
+    if (!c || !c->timed) return -1.f;
+    float ms = -1.f;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+unsigned long long vv_last_sample_count(vv_context *c)
+{
+    if (!c || !c->counter_valid) return 0;
+    unsigned long long v = 0;
+    hipSetDevice(c->device);
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return 0;
+    if (hipMemcpy(&v, c->d_counter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return v;
+}
+
+// ---- slice view: invoke_slice_kernel / invoke_advanced_slice_kernel, kernel.cu:506-541 ----
+static int run_slice(vv_context *c, SliceArgs &S, float *buffer, int out_on_device, void *stream)
+{
+    if (!c) return fail(nullptr, VV_ERR_INVALID, "vv_slice: NULL context");
+    if (!buffer) return fail(c, VV_ERR_INVALID, "vv_slice: NULL buffer");
+    if (!c->d_vol) return fail(c, VV_ERR_NO_VOLUME, "vv_slice: no volume loaded");
+    if (S.height < 1 || S.width < 1 || S.height > 65535u * 16 || S.width > 65535u * 16)
+        return fail(c, VV_ERR_INVALID, "vv_slice: bad buffer size");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const size_t bytes = S.height * S.width * sizeof(float);
+    S.V = view_of(c); S.V_type = c->vtype;
+    float *d = buffer;
+    if (!out_on_device) {
+        // persistent scratch instead of the reference's cudaMalloc/cudaFree per call (kernel.cu:508-518)
+        int rc = ensure(c, (void **)&c->d_slice, &c->slice_cap, bytes);
+        if (rc) return rc;
+        d = c->d_slice;
+        HIPCHK(c, hipMemcpyAsync(d, buffer, bytes, hipMemcpyHostToDevice, st));   // elements the kernel skips keep caller bytes
+    }
+    S.buffer = d;
+    launch_slice(S, st);
+    HIPCHK(c, hipGetLastError());
+    if (!out_on_device) {
+        HIPCHK(c, hipMemcpyAsync(buffer, d, bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    } else if (!stream) HIPCHK(c, hipStreamSynchronize(st));
+    return VV_OK;
+}
+
+int vv_slice(vv_context *c, float *buffer, size_t height, size_t width, float dx, float dy, float dz,
+             int orientation, const float scale[3], int legacy, int filter, int out_on_device, void *stream)
+{
+    if (!scale) return fail(c, VV_ERR_INVALID, "vv_slice: NULL scale");
+    SliceArgs S; memset(&S, 0, sizeof S);
+    S.height = height; S.width = width; S.dx = dx; S.dy = dy; S.dz = dz;
+    S.orientation = orientation; S.legacy = legacy; S.advanced = 0;
+    S.tex8 = filter != VV_FILTER_EXACT;
+    for (int a = 0; a < 3; ++a) S.scale[a] = scale[a];
+    return run_slice(c, S, buffer, out_on_device, stream);
+}
+
+int vv_slice_advanced(vv_context *c, float *buffer, size_t height, size_t width, const float trans[16],
+                      const float scale[3], int filter, int out_on_device, void *stream)
+{
+    if (!scale || !trans) return fail(c, VV_ERR_INVALID, "vv_slice_advanced: NULL argument");
+    SliceArgs S; memset(&S, 0, sizeof S);
+    S.height = height; S.width = width; S.advanced = 1;
+    S.tex8 = filter != VV_FILTER_EXACT;
+    for (int a = 0; a < 3; ++a) S.scale[a] = scale[a];
+    memcpy(S.trans, trans, 16 * sizeof(float));
+    return run_slice(c, S, buffer, out_on_device, stream);
+}
+
+// ---- generator: VolumeGenerator::drawEllipsoid / drawDefaultBrain ------------------------
+int vv_generate_ellipsoids(vv_context *c, uint8_t *out, int out_on_device, int nx, int ny, int nz, int n,
+                           const float *centers, const float *axes, const uint8_t *colors, void *stream)
+{
+    if (!c) return fail(nullptr, VV_ERR_INVALID, "vv_generate_ellipsoids: NULL context");
+    if (!out || nx < 1 || ny < 1 || nz < 1 || n < 0 || n > kMaxEllipsoids || (n > 0 && (!centers || !axes || !colors)))
+        return fail(c, VV_ERR_INVALID, "vv_generate_ellipsoids: bad argument (n <= 64)");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const size_t bytes = (size_t)nx * ny * nz;
+    uint8_t *d = out;
+    void *tmp = nullptr;
+    if (!out_on_device) { HIPCHK(c, hipMalloc(&tmp, bytes)); d = (uint8_t *)tmp; }
+    if (((uintptr_t)d & 15) != 0) { if (tmp) hipFree(tmp); return fail(c, VV_ERR_INVALID, "vv_generate_ellipsoids: device buffer must be 16-byte aligned"); }
+    launch_generate_ellipsoids(d, nx, ny, nz, n, centers, axes, colors, st);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && !out_on_device) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && (!out_on_device || !stream)) e = hipStreamSynchronize(st);
+    if (tmp) hipFree(tmp);
+    if (e != hipSuccess) return fail(c, VV_ERR_DEVICE, std::string("vv_generate_ellipsoids: ") + hipGetErrorString(e));
+    return VV_OK;
+}
+
+int vv_generate_default_brain(vv_context *c, uint8_t *out, int out_on_device, int nx, int ny, int nz, void *stream)
+{
+    // volumegenerator.cpp:100-119: centre-major, layer-minor; later ellipsoids overwrite earlier
+    static const float centers2[2][3] = { {0.25f, 0.50f, 0.50f}, {0.75f, 0.50f, 0.50f} };
+    static const float layers4[4][3]  = { {0.23f, 0.30f, 0.45f}, {0.18f, 0.27f, 0.40f},
+                                          {0.10f, 0.23f, 0.30f}, {0.03f, 0.20f, 0.20f} };
+    static const uint8_t shades4[4] = { 60, 80, 100, 120 };
+    float centers[8 * 3], axes[8 * 3]; uint8_t colors[8];
+    int e = 0;
+    for (int ci = 0; ci < 2; ++ci) for (int li = 0; li < 4; ++li, ++e) {
+        for (int a = 0; a < 3; ++a) { centers[3*e+a] = centers2[ci][a]; axes[3*e+a] = layers4[li][a]; }
+        colors[e] = shades4[li];
+    }
+    return vv_generate_ellipsoids(c, out, out_on_device, nx, ny, nz, 8, centers, axes, colors, stream);
+}
+
+int vv_promote_u8_to_f32(vv_context *c, const uint8_t *dev_in, float *dev_out, size_t n, void *stream)
+{
+    if (!c || !dev_in || !dev_out) return fail(c, VV_ERR_INVALID, "vv_promote_u8_to_f32: NULL argument");
+    if (((uintptr_t)dev_in & 15) || ((uintptr_t)dev_out & 15)) return fail(c, VV_ERR_INVALID, "vv_promote_u8_to_f32: buffers must be 16-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    launch_promote_u8_f32(dev_in, dev_out, n, st);
+    HIPCHK(c, hipGetLastError());
+    if (!stream) HIPCHK(c, hipStreamSynchronize(st));
+    return VV_OK;
+}
+
+int vv_generate_noise_u8(vv_context *c, uint8_t *dev_out, int nx, int ny, int nz, uint32_t seed, void *stream)
+{
+    if (!c || !dev_out || nx < 1 || ny < 1 || nz < 1) return fail(c, VV_ERR_INVALID, "vv_generate_noise_u8: bad argument");
+    if ((size_t)nx * ny * nz > 0xFFFFFFFFull) return fail(c, VV_ERR_INVALID, "vv_generate_noise_u8: volume too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    launch_noise_u8(dev_out, nx, ny, nz, seed, st);
+    HIPCHK(c, hipGetLastError());
+    if (!stream) HIPCHK(c, hipStreamSynchronize(st));
+    return VV_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,205 @@
+// vv_aux.hip -- slice-view sampler, procedural generator and volume staging kernels
+// for gfx950.
+//
+//   slice_kernel          kernel.cu:543-597 (5-arg), slicekernel.cu:51-82 (legacy 4-arg)
+//   advanced_slice_kernel kernel.cu:599-644
+//   ellipsoid_kernel      VolumeGenerator::drawEllipsoid, volumegenerator.cpp:31-97,
+//                         n ellipsoids fused into one pass over the volume
+#include "vv_device.h"
+#include "vv_kernels.h"
+
+namespace vv {
+
+// ---------------------------------------------------------------------------
+// slice view
+// ---------------------------------------------------------------------------
+template <int VOXEL, bool TEX8>
+__global__ __launch_bounds__(256) void slice_kernel(SliceArgs A)
+{
+#pragma clang fp contract(off)
+    const size_t i = threadIdx.x + (size_t)blockIdx.x * 16;      // 16x16 threads, as the reference
+    const size_t j = threadIdx.y + (size_t)blockIdx.y * 16;
+    if (!(j < A.height && i < A.width)) return;                   // kernel.cu:552
+    const size_t offset = j * A.height + i;                       // kernel.cu:550,604 (height as stride)
+    if (offset >= A.height * A.width) return;                     // the reference would write out of bounds
+    const float u = ((float)i) / ((float)A.width), w = ((float)j) / ((float)A.height);
+    float px, py, pz;
+    bool check = true;
+    if (A.advanced) {
+        const float rz = 0.5f, rw = 1.f;                          // kernel.cu:608-618, row-major matrix
+        px = A.trans[0] * u + A.trans[1] * w + A.trans[2]  * rz + A.trans[3]  * rw;
+        py = A.trans[4] * u + A.trans[5] * w + A.trans[6]  * rz + A.trans[7]  * rw;
+        pz = A.trans[8] * u + A.trans[9] * w + A.trans[10] * rz + A.trans[11] * rw;
+        px /= A.scale[0]; py /= A.scale[1]; pz /= A.scale[2];     // :620-622
+        px = (px - 0.5f) / A.scale[0] + 0.5f;                     // :624 (scaled a second time)
+        py = (py - 0.5f) / A.scale[1] + 0.5f;
+        pz = (pz - 0.5f) / A.scale[2] + 0.5f;
+    } else {
+        px = 0.f; py = 0.f; pz = 0.f;
+        if (A.legacy) { px = u; py = w; pz = 0.f; }               // slicekernel.cu:62-64
+        else switch (A.orientation) {                             // kernel.cu:559-579
+            case VV_SAGITTAL:   pz += 0.f; py += w;   px += u;   break;
+            case VV_HORIZONTAL: pz += u;   py += 0.f; px += w;   break;
+            case VV_CORONAL:    pz += u;   py += w;   px += 0.f; break;
+            default: break;
+        }
+        px += A.dx; py += A.dy; pz += A.dz;                       // :581-583
+        if (A.legacy) check = false;                              // slicekernel.cu:70: unconditional fetch
+        else {
+            px = (px - 0.5f) / A.scale[0] + 0.5f;                 // :585
+            py = (py - 0.5f) / A.scale[1] + 0.5f;
+            pz = (pz - 0.5f) / A.scale[2] + 0.5f;
+        }
+    }
+    float s = 0.f;
+    if (!check || (px < 1.0f && px >= 0.0f && py < 1.0f && py >= 0.0f && pz < 1.0f && pz >= 0.0f)) {
+        float L = tex3d_raw<VOXEL, TEX8>(A.V, px, py, pz);
+        s = (VOXEL == VV_VOXEL_U8) ? L / 255.0f : L;              // normalised-float read mode, kernel.cu:46
+    }
+    A.buffer[offset] = s;
+}
+
+void launch_slice(const SliceArgs &a, hipStream_t s)
+{
+    dim3 block(16, 16), grid((unsigned)((a.width + 15) / 16), (unsigned)((a.height + 15) / 16));
+    if (a.V_type == VV_VOXEL_F32) {
+        if (a.tex8) hipLaunchKernelGGL((slice_kernel<VV_VOXEL_F32, true>), grid, block, 0, s, a);
+        else        hipLaunchKernelGGL((slice_kernel<VV_VOXEL_F32, false>), grid, block, 0, s, a);
+    } else {
+        if (a.tex8) hipLaunchKernelGGL((slice_kernel<VV_VOXEL_U8, true>), grid, block, 0, s, a);
+        else        hipLaunchKernelGGL((slice_kernel<VV_VOXEL_U8, false>), grid, block, 0, s, a);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// generator
+// ---------------------------------------------------------------------------
+struct EllipsoidSet {
+    int n;
+    float cx[kMaxEllipsoids], cy[kMaxEllipsoids], cz[kMaxEllipsoids];
+    float ax[kMaxEllipsoids], ay[kMaxEllipsoids], az[kMaxEllipsoids];
+    uint8_t color[kMaxEllipsoids];
+};
+
+// One thread produces 16 consecutive x voxels of one (j,k) row: the y and z terms of
+// every ellipsoid are computed once per thread, the store is one 16-byte write.
+// All arithmetic is uncontracted binary32 with IEEE division, as g++ compiles
+// volumegenerator.cpp:44-59, so the output is bit-identical.
+__global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ out, int nx, int ny, int nz,
+                                                        int xchunks, EllipsoidSet E)
+{
+#pragma clang fp contract(off)
+    const size_t total = (size_t)xchunks * ny * nz;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int xc = (int)(t % xchunks);
+        const size_t row = t / xchunks;
+        const int j = (int)(row % ny), k = (int)(row / ny);
+        const float fj = ((float)j) / ((float)ny), fk = ((float)k) / ((float)nz);   // :45-46
+        const int i0 = xc * 16;
+        uint32_t packed[4] = {0u, 0u, 0u, 0u};
+        uint8_t vals[16];
+        for (int v = 0; v < 16; ++v) vals[v] = 0;                                   // ctor zero-fill :12-23
+        for (int e = 0; e < E.n; ++e) {
+            const float ey = (E.cy[e] - fj) / E.ay[e], ez = (E.cz[e] - fk) / E.az[e];
+            const float eyy = ey * ey, ezz = ez * ez;
+            for (int v = 0; v < 16; ++v) {
+                const float fi = ((float)(i0 + v)) / ((float)nx);                   // :44
+                const float ex = (E.cx[e] - fi) / E.ax[e];
+                const float q = ((ex * ex) + eyy) + ezz;                            // :57-59
+                if ((double)q < 1.0) vals[v] = E.color[e];
+                if ((double)fi >= 0.99) vals[v] = 4;                                // :85-87
+            }
+        }
+        const size_t base = row * (size_t)nx + i0;
+        if (i0 + 16 <= nx && (base & 15) == 0) {
+            for (int v = 0; v < 16; ++v) packed[v >> 2] |= (uint32_t)vals[v] << (8 * (v & 3));
+            *(uint4 *)(out + base) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        } else {
+            for (int v = 0; v < 16 && i0 + v < nx; ++v) out[base + v] = vals[v];
+        }
+    }
+}
+
+void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
+                                const float *centers, const float *axes, const uint8_t *colors,
+                                hipStream_t s)
+{
+    EllipsoidSet E;
+    E.n = n;
+    for (int e = 0; e < n; ++e) {
+        E.cx[e] = centers[3*e]; E.cy[e] = centers[3*e+1]; E.cz[e] = centers[3*e+2];
+        E.ax[e] = axes[3*e];    E.ay[e] = axes[3*e+1];    E.az[e] = axes[3*e+2];
+        E.color[e] = colors[e];
+    }
+    const int xchunks = (nx + 15) / 16;
+    const size_t total = (size_t)xchunks * ny * nz;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(ellipsoid_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, nx, ny, nz, xchunks, E);
+}
+
+// ---------------------------------------------------------------------------
+// u8 -> f32 promotion (v / 255), 16 voxels per thread
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void promote_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, size_t n)
+{
+    const size_t nchunks = n / 16;
+    for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < nchunks; c += (size_t)gridDim.x * blockDim.x) {
+        uint4 p = *(const uint4 *)(in + c * 16);
+        const uint32_t w[4] = {p.x, p.y, p.z, p.w};
+        float4 *o = (float4 *)(out + c * 16);
+        for (int q = 0; q < 4; ++q)
+            o[q] = make_float4((float)(w[q] & 0xff) / 255.f, (float)((w[q] >> 8) & 0xff) / 255.f,
+                               (float)((w[q] >> 16) & 0xff) / 255.f, (float)(w[q] >> 24) / 255.f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 15)) {
+        size_t i = nchunks * 16 + threadIdx.x;
+        out[i] = (float)in[i] / 255.f;
+    }
+}
+
+void launch_promote_u8_f32(const uint8_t *in, float *out, size_t n, hipStream_t s)
+{
+    size_t blocks = (n / 16 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(promote_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n);
+}
+
+// ---------------------------------------------------------------------------
+// synthetic noise volume V2 (measurement input, not from the reference)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void noise_kernel(uint8_t *__restrict__ out, int nx, int ny, int nz, uint32_t seed)
+{
+    const size_t total = (size_t)nx * ny * nz;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(t % nx);
+        const size_t row = t / nx;
+        const int y = (int)(row % ny), z = (int)(row / ny);
+        uint32_t sum = 0;
+        for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+            int xx = max(0, min(x + dx, nx - 1)), yy = max(0, min(y + dy, ny - 1)), zz = max(0, min(z + dz, nz - 1));
+            uint32_t idx = (uint32_t)xx + (uint32_t)nx * ((uint32_t)yy + (uint32_t)ny * (uint32_t)zz);
+            sum += mix32(idx ^ seed) >> 24;
+        }
+        out[t] = (uint8_t)((sum + 13u) / 27u);
+    }
+}
+
+void launch_noise_u8(uint8_t *out, int nx, int ny, int nz, uint32_t seed, hipStream_t s)
+{
+    size_t total = (size_t)nx * ny * nz;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(noise_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, nx, ny, nz, seed);
+}
+
+} // namespace vv

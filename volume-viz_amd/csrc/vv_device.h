@@ -1,0 +1,291 @@
+// vv_device.h -- device-side building blocks shared by the HIP kernels (gfx950 only).
+//
+// Reference semantics restated here (citations relative to jacobstern/volume-viz):
+//   ray end points      kernel.cu:317-321, firstpass.vert:6, glwidget.cpp:198-228,338
+//   ray set-up          kernel.cu:323-350, implicit.cu:20-35
+//   plane clipping      kernel.cu:234-246, implicit.cu:4-17,38-47
+//   texture unit        kernel.cu:46,99-105,485-489 (tex3D linear/clamp/normalised)
+//
+// Arithmetic that feeds per-ray set-up is written without FMA contraction so that it
+// reproduces the strict-float order of the source; the per-sample texture model uses
+// explicit fmaf (the reference does this in hardware).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/volviz.h"
+
+namespace vv {
+
+constexpr int   kCacheDepth = 32;          // kernel.cu:24
+constexpr float kChunkSteps = 30.f;        // kernel.cu:25
+constexpr int   kSlab = 14;                // BLOCK_WIDTH-2, kernel.cu:30,418
+constexpr int   kBlock = 16;               // kernel.cu:30-31
+constexpr float kSqrt3 = 1.73205081f;      // kernel.cu:33
+// float thresholds equivalent to the reference's double-literal comparisons:
+//   (double)f > 1e-6  <=>  f >  kEps   ;  (double)f < 1e-6  <=>  f <= kEps
+//   (double)t > -1e-6 <=>  t >= -kEps      (kEps = (float)1e-6 = 0x358637BD < 1e-6)
+constexpr float kEps = 1e-6f;
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+
+// Volume as laid out in HBM: linear, x fastest, rows/slices contiguous, with one
+// row + one slice + 16 bytes of zero padding past the end so that the (weight-0)
+// upper corner of an edge sample may be fetched without clamping the index.
+struct VolumeView {
+    const void *data;
+    int nx, ny, nz;
+    uint32_t row_bytes;     // nx * sizeof(voxel)
+    uint32_t slice_bytes;   // nx*ny * sizeof(voxel)
+};
+
+// Everything a frame needs that is uniform over the launch.
+struct FrameParams {
+    int W, H;
+    int nbx, nby;                 // slab grid, kernel.cu:418-425
+    int conflict_x, conflict_y;   // W-1 == 14*(nbx-1) (resp. H): last block re-writes a pixel
+    int y_begin, y_end;           // pixel rows rendered by this call (slab-row shard)
+    int slice_type;
+    float slice_point[3], slice_normal[3];
+    float cam_pos[3], scale[3], inv_scale[3];
+    float step[3];
+    float tan_fov_x, tan_fov_y;   // kernel.cu:221-222 (computed in double on the host)
+    float ert_thr;
+    int   ert_true;
+    int   max_chunks;             // hard bound on the chunk loop (every wave exits)
+    // ray source
+    int ray_mode, quantize8;
+    const uint8_t *front_img, *back_img; int img_w, img_h;
+    float side[3], up[3], look[3];   // orthonormal camera basis (camera.cpp:78-91)
+    float tan_half_x, tan_half_y;    // tan(fovY/2)*aspect, tan(fovY/2)
+};
+
+// ---------------------------------------------------------------------------
+// strict (uncontracted) helpers for per-ray set-up
+// ---------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__device__ __forceinline__ float vlen3(float x, float y, float z)
+{
+#pragma clang fp contract(off)
+    return __fsqrt_rn(x * x + y * y + z * z);       // kernel.cu:53-57
+}
+__device__ __forceinline__ float dot3s(f3 a, f3 b)
+{
+#pragma clang fp contract(off)
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+
+// Pixel -> front/back end points.  Mirrors oracle analytic_endpoints / image_endpoints.
+__device__ __forceinline__ void ray_endpoints(const FrameParams &P, int x, int y, f3 &front, f3 &back)
+{
+#pragma clang fp contract(off)
+    if (P.ray_mode == VV_RAYS_IMAGES) {
+        // kernel.cu:317-321: tex2D point sampling at normalised (x/W, y/H)
+        float u = (float)x / (float)P.W, v = (float)y / (float)P.H;
+        int tx = (int)floorf(u * (float)P.img_w), ty = (int)floorf(v * (float)P.img_h);
+        tx = max(0, min(tx, P.img_w - 1)); ty = max(0, min(ty, P.img_h - 1));
+        const uint8_t *f = P.front_img + 4 * ((size_t)ty * P.img_w + tx);
+        const uint8_t *b = P.back_img  + 4 * ((size_t)ty * P.img_w + tx);
+        front = mk3(f[0] / 255.f, f[1] / 255.f, f[2] / 255.f);
+        back  = mk3(b[0] / 255.f, b[1] / 255.f, b[2] / 255.f);
+        return;
+    }
+    float ndx = (2.0f * ((float)x + 0.5f)) / (float)P.W - 1.0f;
+    float ndy = (2.0f * ((float)y + 0.5f)) / (float)P.H - 1.0f;
+    float sx = ndx * P.tan_half_x, sy = ndy * P.tan_half_y;
+    float d[3], o[3] = {P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]};
+    for (int a = 0; a < 3; a++) d[a] = (P.side[a] * sx + P.up[a] * sy) + P.look[a];
+    float tmin = -INFINITY, tmax = INFINITY;
+    bool miss = false;
+    for (int a = 0; a < 3; a++) {
+        float s = P.scale[a];
+        if (d[a] != 0.0f) {
+            float t1 = (-s - o[a]) / d[a], t2 = (s - o[a]) / d[a];
+            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+        } else if (o[a] < -s || o[a] > s) miss = true;
+    }
+    front = mk3(0.f, 0.f, 0.f); back = mk3(0.f, 0.f, 0.f);
+    if (miss || !(tmin <= tmax) || !(tmax > 0.0f)) return;
+    back = mk3((o[0] + d[0] * tmax) * 0.5f + 0.5f, (o[1] + d[1] * tmax) * 0.5f + 0.5f,
+               (o[2] + d[2] * tmax) * 0.5f + 0.5f);
+    if (tmin > 0.0f)
+        front = mk3((o[0] + d[0] * tmin) * 0.5f + 0.5f, (o[1] + d[1] * tmin) * 0.5f + 0.5f,
+                    (o[2] + d[2] * tmin) * 0.5f + 0.5f);
+    if (P.quantize8) {
+        float *p[6] = {&front.x, &front.y, &front.z, &back.x, &back.y, &back.z};
+        for (int i = 0; i < 6; i++) {
+            float c = fmaxf(0.f, fminf(*p[i], 1.f));
+            *p[i] = floorf(c * 255.0f + 0.5f) / 255.f;
+        }
+    }
+}
+
+// Slab footprint of block b along one axis (kernel.cu:297-302) and the write-owner
+// rule (oracle pin 10).
+__device__ __host__ __forceinline__ int slab_lo(int b) { int v = b * kSlab - 1; return v < 0 ? 0 : v; }
+__device__ __host__ __forceinline__ int slab_up(int b, int n) { int v = (b + 1) * kSlab + 1; return v > n - 1 ? n - 1 : v; }
+__device__ __host__ __forceinline__ int owner_slab(int p, int n, int nb, int conflict)
+{
+    return (conflict && p == n - 2) ? nb - 1 : p / kSlab;
+}
+
+struct Ray {
+    f3 origin, dir, sdir;
+    float sstep, upper, dist0;
+    bool cut_return;
+};
+
+// kernel.cu:331-350 + the head of mainLoop (kernel.cu:228-246)
+__device__ __forceinline__ void setup_ray(const FrameParams &P, f3 front, f3 back, float rad, Ray &r)
+{
+#pragma clang fp contract(off)
+    f3 cam = mk3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    float dx = back.x - front.x, dy = back.y - front.y, dz = back.z - front.z;
+    float length = vlen3(dx, dy, dz);
+    f3 ray = mk3(dx / length, dy / length, dz / length);          // :340
+    f3 pos = front;
+    {   // implicit.cu:20-35 with l = -ray
+        f3 l = mk3(ray.x * -1.f, ray.y * -1.f, ray.z * -1.f);
+        f3 l0p0 = mk3(front.x - cam.x, front.y - cam.y, front.z - cam.z);
+        float b = dot3s(l, l0p0);
+        float c = dot3s(l0p0, l0p0) - rad * rad;
+        float disc = b * b - c;
+        if (disc >= 0.f) {
+            float t = b * -1.f - __fsqrt_rn(disc);
+            if (t >= -kEps) pos = mk3(pos.x - ray.x * t, pos.y - ray.y * t, pos.z - ray.z * t);  // :347
+        }
+    }
+    float upper = fminf(kSqrt3, vlen3(back.x - pos.x, back.y - pos.y, back.z - pos.z));   // :350
+    r.origin = pos; r.dir = ray;
+    r.sdir = mk3(ray.x * P.step[0], ray.y * P.step[1], ray.z * P.step[2]);                // :228
+    r.sstep = vlen3(r.sdir.x, r.sdir.y, r.sdir.z);                                        // :229
+    r.dist0 = 0.f; r.cut_return = false;
+    if (P.slice_type == SLICE_PLANE_CUT) {                                                // :234-246
+        f3 p0 = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
+        f3 n  = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
+        f3 bk = mk3(pos.x + ray.x * upper, pos.y + ray.y * upper, pos.z + ray.z * upper);
+        float sf = dot3s(n, mk3(pos.x - p0.x, pos.y - p0.y, pos.z - p0.z));
+        float sb = dot3s(n, mk3(bk.x - p0.x, bk.y - p0.y, bk.z - p0.z));
+        if (sf <= kEps && sb <= kEps) {
+            r.cut_return = true;
+        } else {
+            float denom = dot3s(n, ray);
+            bool hit = false;
+            if (denom > kEps) {                                   // implicit.cu:4-17 (origin, ray)
+                float t = dot3s(mk3(p0.x - pos.x, p0.y - pos.y, p0.z - pos.z), n) / denom;
+                if (t >= 0.f) { r.dist0 = t; hit = true; }
+            }
+            if (!hit) {
+                f3 nr = mk3(ray.x * -1.f, ray.y * -1.f, ray.z * -1.f);
+                float den2 = dot3s(n, nr);
+                if (den2 > kEps) {                                // (back, -ray)
+                    float t = dot3s(mk3(p0.x - bk.x, p0.y - bk.y, p0.z - bk.z), n) / den2;
+                    if (t >= 0.f) upper -= t;
+                }
+            }
+        }
+    }
+    r.upper = upper;
+}
+
+// Number of inner-loop iterations i = 1..30 that pass `i*sstep + dist <= upper`
+// (kernel.cu:253-257), evaluated with the reference's own float expression so the
+// count is exact; the predicate is monotone in i.
+__device__ __forceinline__ int chunk_count(float dist, float upper, float sstep)
+{
+#pragma clang fp contract(off)
+    if (!(dist < upper)) return 0;                  // while (dist < upper), kernel.cu:248
+    // the predicate must hold for i to be counted; NaN compares false -> stop
+    float est = (upper - dist) / sstep;
+    int n = est >= 30.f ? 30 : (est > 0.f ? (int)est : 0);
+    while (n < 30 && !((float)(n + 1) * sstep + dist > upper)) ++n;
+    while (n > 0 && ((float)n * sstep + dist > upper)) --n;
+    // NaN step: predicate `voxelDist > upper` is false for every i -> all 30 run
+    if (sstep != sstep) n = 30;
+    return n;
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------
+// texture unit model (mirrors oracle tex3d_raw)
+// ---------------------------------------------------------------------------
+typedef float  __attribute__((ext_vector_type(2), aligned(4))) float2u;   // 4-byte aligned pair
+typedef unsigned short __attribute__((aligned(1))) ushort_u;
+
+template <bool TEX8>
+__device__ __forceinline__ float axis_coord(float x, float n, float nm1, uint32_t &i)
+{
+    float xb = __builtin_fmaf(x, n, -0.5f);
+    // clamp addressing: for xb < 0 the result is texel 0, for xb >= n-1 texel n-1;
+    // clamping the coordinate gives the same value with weight 0.
+    xb = __builtin_amdgcn_fmed3f(xb, 0.0f, nm1);
+    float fl = floorf(xb);
+    float a = xb - fl;
+    i = (uint32_t)fl;
+    if (TEX8) {
+        // round to 8 fractional bits, ties to even: adding 1.5*2^15 makes ulp = 2^-8
+        const float magic = 49152.0f;
+        float t = a + magic;
+        a = t - magic;
+    }
+    return a;
+}
+
+// Trilinear reconstruction in storage units (0..255 for u8, as-is for f32) at
+// normalised texture coordinates p (any value; out-of-range is clamped, NaN -> texel 0).
+template <int VOXEL, bool TEX8>
+__device__ __forceinline__ float tex3d_raw(const VolumeView &V, float px, float py, float pz)
+{
+    uint32_t ix, iy, iz;
+    float wx = axis_coord<TEX8>(px, (float)V.nx, (float)(V.nx - 1), ix);
+    float wy = axis_coord<TEX8>(py, (float)V.ny, (float)(V.ny - 1), iy);
+    float wz = axis_coord<TEX8>(pz, (float)V.nz, (float)(V.nz - 1), iz);
+    const char *b00 = (const char *)V.data;
+    const char *b10 = b00 + V.row_bytes;
+    const char *b01 = b00 + V.slice_bytes;
+    const char *b11 = b01 + V.row_bytes;
+    float c000, c100, c010, c110, c001, c101, c011, c111;
+    if (VOXEL == VV_VOXEL_F32) {
+        uint32_t off = ix * 4u + iy * V.row_bytes + iz * V.slice_bytes;
+        float2u a = *(const float2u *)(b00 + off), b = *(const float2u *)(b10 + off);
+        float2u c = *(const float2u *)(b01 + off), d = *(const float2u *)(b11 + off);
+        c000 = a.x; c100 = a.y; c010 = b.x; c110 = b.y; c001 = c.x; c101 = c.y; c011 = d.x; c111 = d.y;
+    } else {
+        uint32_t off = ix + iy * V.row_bytes + iz * V.slice_bytes;
+        uint32_t a = *(const ushort_u *)(b00 + off), b = *(const ushort_u *)(b10 + off);
+        uint32_t c = *(const ushort_u *)(b01 + off), d = *(const ushort_u *)(b11 + off);
+        c000 = (float)(a & 0xffu); c100 = (float)(a >> 8); c010 = (float)(b & 0xffu); c110 = (float)(b >> 8);
+        c001 = (float)(c & 0xffu); c101 = (float)(c >> 8); c011 = (float)(d & 0xffu); c111 = (float)(d >> 8);
+    }
+    float c00 = __builtin_fmaf(wx, c100 - c000, c000);
+    float c10 = __builtin_fmaf(wx, c110 - c010, c010);
+    float c01 = __builtin_fmaf(wx, c101 - c001, c001);
+    float c11 = __builtin_fmaf(wx, c111 - c011, c011);
+    float c0 = __builtin_fmaf(wy, c10 - c00, c00);
+    float c1 = __builtin_fmaf(wy, c11 - c01, c01);
+    return __builtin_fmaf(wz, c1 - c0, c0);
+}
+
+// kernel.cu:65-71 boundsCheck on all three coordinates: p in [0,1).  A float is in
+// [0,1) iff its bit pattern, read as unsigned, is below 0x3F800000 (negatives and
+// NaNs have larger patterns; -0.0 cannot arise from (x-.5)/s+.5 in round-to-nearest).
+__device__ __forceinline__ bool bounds_check(float x, float y, float z)
+{
+    uint32_t m = max(max(__float_as_uint(x), __float_as_uint(y)), __float_as_uint(z));
+    return m < 0x3F800000u;
+}
+
+// kernel.cu:99-105 sample(): (uchar)(0xff * tex3D) or 0 outside.  For u8 volumes
+// 255 * (L/255) truncates to trunc(L) except when L is within 1 ulp below an
+// integer (p ~ 1e-5 per sample), so the classification index is
+// taken from L directly.
+template <int VOXEL, bool TEX8>
+__device__ __forceinline__ uint32_t sample_index(const VolumeView &V, float px, float py, float pz)
+{
+    float L = tex3d_raw<VOXEL, TEX8>(V, px, py, pz);
+    float s = (VOXEL == VV_VOXEL_F32) ? L * 255.0f : L;
+    uint32_t idx = min((uint32_t)s, 255u);          // v_cvt_u32_f32 saturates; NaN -> 0
+    return bounds_check(px, py, pz) ? idx : 0u;
+}
+
+} // namespace vv

@@ -1,0 +1,132 @@
+// vv_host.cpp -- host-only parts of the C-ABI: transfer-function presets and the
+// .t3d container.  No device code.
+//
+//   vv_transfer_preset : transfer_functions.h:4-9 (g_transferEngine/Head/Mri) as closed
+//                        forms evaluated in double and narrowed to float; bit-identical
+//                        to the header's tables (tests/golden/tf_*.f32).
+//   vv_t3d_*           : VolumeGenerator::saveas_raw / loadfrom_raw
+//                        (volumegenerator.cpp:147-220) and utils/{read,write}size.cpp:
+//                        optional header of three native-endian 64-bit sizes x,y,z
+//                        followed by x*y*z bytes, x fastest.
+#include "../../include/volviz.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+void tent(float tf[1024], double up, double dn)
+{
+    for (int i = 0; i < 256; ++i) {
+        double v;
+        if (i < 77) v = 0.0;
+        else if (i <= 153) { v = 0.9 - up * (double)(153 - i) / 255.0; if (v < 0.1) v = 0.1; }
+        else               { v = 0.9 - dn * (double)(i - 153) / 255.0; if (v < 0.1) v = 0.1; }
+        tf[4*i] = tf[4*i+1] = tf[4*i+2] = (float)v;
+        tf[4*i+3] = (float)(0.05 * v);
+    }
+}
+}
+
+extern "C" {
+
+int vv_transfer_preset(int preset, float tf[1024])
+{
+    if (!tf) return VV_ERR_INVALID;
+    switch (preset) {
+    case VV_TF_ENGINE:
+        for (int i = 0; i < 256; ++i) {
+            double x = (double)i / 255.0, a = 2.0 * (x * x);
+            if (a > 1.0) a = 1.0;
+            tf[4*i] = tf[4*i+1] = tf[4*i+2] = (float)x;
+            tf[4*i+3] = (float)a;
+        }
+        return VV_OK;
+    case VV_TF_HEAD: tent(tf, 4.0, 2.0); return VV_OK;
+    case VV_TF_MRI:  tent(tf, 4.6, 2.6); return VV_OK;
+    default: return VV_ERR_INVALID;
+    }
+}
+
+// slicewidget.cpp:147-165 with the float algebra of cs123math (REAL == float)
+int vv_slice_matrix(float dx, float dy, float dz, float theta, float phi, float psi, float out[16])
+{
+    if (!out) return VV_ERR_INVALID;
+    const float ang[3] = {theta, phi, psi};
+    for (float a : ang) if (!(a >= -3.2f && a < 3.2f)) return VV_ERR_INVALID;   // slicewidget.cpp:149-154
+    auto mul = [](const float a[16], const float b[16], float r[16]) {
+        float t[16];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                t[4*i+j] = a[4*i] * b[j] + a[4*i+1] * b[4+j] + a[4*i+2] * b[8+j] + a[4*i+3] * b[12+j];
+        memcpy(r, t, sizeof t);
+    };
+    auto trans = [](float x, float y, float z, float m[16]) {
+        const float t[16] = {1, 0, 0, x, 0, 1, 0, y, 0, 0, 1, z, 0, 0, 0, 1};
+        memcpy(m, t, sizeof t);
+    };
+    const float ct = cosf(theta), st = sinf(theta), cp = cosf(phi), sp = sinf(phi), cs = cosf(psi), ss = sinf(psi);
+    const float rx[16] = {1, 0, 0, 0, 0, ct, -st, 0, 0, st, ct, 0, 0, 0, 0, 1};
+    const float ry[16] = {cp, 0, sp, 0, 0, 1, 0, 0, -sp, 0, cp, 0, 0, 0, 0, 1};
+    const float rz[16] = {cs, -ss, 0, 0, ss, cs, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float m[16], t[16];
+    trans(0.5f, 0.5f, 0.5f, m);
+    trans(dx, dy, dz, t); mul(m, t, m);
+    mul(m, rx, m); mul(m, ry, m); mul(m, rz, m);
+    trans(-0.5f, -0.5f, -0.5f, t); mul(m, t, m);
+    memcpy(out, m, sizeof m);
+    return VV_OK;
+}
+
+// header-less files are 128 x 256 x 256 (volumegenerator.cpp:204-208)
+int vv_t3d_read_header(const char *path, int header, int *nx, int *ny, int *nz)
+{
+    if (!path || !nx || !ny || !nz) return VV_ERR_INVALID;
+    if (!header) { *nx = 128; *ny = 256; *nz = 256; return VV_OK; }
+    FILE *f = fopen(path, "rb");
+    if (!f) return VV_ERR_IO;
+    uint64_t d[3];
+    size_t got = fread(d, sizeof(uint64_t), 3, f);
+    fclose(f);
+    if (got != 3) return VV_ERR_IO;
+    if (d[0] == 0 || d[1] == 0 || d[2] == 0 || d[0] > 0x7fffffffu || d[1] > 0x7fffffffu || d[2] > 0x7fffffffu)
+        return VV_ERR_INVALID;
+    *nx = (int)d[0]; *ny = (int)d[1]; *nz = (int)d[2];
+    return VV_OK;
+}
+
+int vv_t3d_read(const char *path, int header, uint8_t *dst, size_t capacity)
+{
+    int nx, ny, nz;
+    int rc = vv_t3d_read_header(path, header, &nx, &ny, &nz);
+    if (rc) return rc;
+    const size_t n = (size_t)nx * ny * nz;
+    if (!dst || capacity < n) return VV_ERR_INVALID;
+    FILE *f = fopen(path, "rb");
+    if (!f) return VV_ERR_IO;
+    if (header && fseek(f, 3 * sizeof(uint64_t), SEEK_SET) != 0) { fclose(f); return VV_ERR_IO; }
+    size_t got = fread(dst, 1, n, f);
+    fclose(f);
+    // a short file leaves the tail as it was, like ifstream::read in the reference;
+    // report it so callers can tell
+    return got == n ? VV_OK : VV_ERR_IO;
+}
+
+int vv_t3d_write(const char *path, int header, const uint8_t *src, int nx, int ny, int nz)
+{
+    if (!path || !src || nx < 1 || ny < 1 || nz < 1) return VV_ERR_INVALID;
+    FILE *f = fopen(path, "wb");
+    if (!f) return VV_ERR_IO;
+    bool ok = true;
+    if (header) {
+        uint64_t d[3] = {(uint64_t)nx, (uint64_t)ny, (uint64_t)nz};
+        ok = fwrite(d, sizeof(uint64_t), 3, f) == 3;
+    }
+    const size_t n = (size_t)nx * ny * nz;
+    ok = ok && fwrite(src, 1, n, f) == n;
+    ok = (fclose(f) == 0) && ok;
+    return ok ? VV_OK : VV_ERR_IO;
+}
+
+} // extern "C"

@@ -1,0 +1,42 @@
+// vv_kernels.h -- host-visible launch interface of the HIP kernels (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vv_device.h"
+
+namespace vv {
+
+struct MarchArgs {
+    FrameParams P;
+    VolumeView  V;
+    int V_type;                 // vv_voxel_type
+    bool tex8, gray, phong, instr;
+    int slab_row_begin, slab_row_end;
+    const float4 *tf;           // device, 256 entries
+    const float *rad;           // device, nbx*nby (read by march_kernel)
+    float *rad_out;             // same buffer (written by rad_kernel)
+    uint32_t *pixels;           // device RGBA8 frame
+    unsigned long long *counter;
+    uint32_t *bricks;
+};
+
+void launch_rad(const MarchArgs &a, hipStream_t s);
+void launch_raymarch(const MarchArgs &a, hipStream_t s);
+
+struct SliceArgs {
+    VolumeView V; int V_type; bool tex8;
+    float *buffer; size_t height, width;
+    float dx, dy, dz; int orientation; int legacy;
+    float scale[3];
+    float trans[16]; int advanced;
+};
+void launch_slice(const SliceArgs &a, hipStream_t s);
+
+void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
+                                const float *centers, const float *axes, const uint8_t *colors,
+                                hipStream_t s);
+void launch_promote_u8_f32(const uint8_t *in, float *out, size_t n, hipStream_t s);
+void launch_noise_u8(uint8_t *out, int nx, int ny, int nz, uint32_t seed, hipStream_t s);
+
+constexpr int kMaxEllipsoids = 64;
+
+} // namespace vv

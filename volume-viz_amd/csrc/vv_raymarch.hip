@@ -1,0 +1,401 @@
+// vv_raymarch.hip -- front-to-back ray-march kernels for gfx950 (MI355X).
+//
+// Replaces kernel<_sliceType> and its device functions (kernel.cu:80-367).  Not a
+// translation: the reference runs one 16x16 block per 14x14 slab with an LDS byte
+// cache and hardware texture fetches; here
+//   * rad_kernel      computes the per-slab sphere radius (blockMin, kernel.cu:80-97,329)
+//                     once, so the march itself is free of the slab tiling;
+//   * march_kernel    (no Phong) gives every wavefront an 8x8 pixel tile, keeps the
+//                     whole ray state in registers, reconstructs samples with a
+//                     branch-free hand-written trilinear gather from linear HBM, and
+//                     classifies through a transfer-function table staged in LDS;
+//   * march_phong_kernel keeps the slab+apron structure that central differences
+//                     across neighbouring rays need (kernel.cu:167-173) with the
+//                     32-deep LDS sample cache.
+#include "vv_device.h"
+#include "vv_kernels.h"
+
+namespace vv {
+
+// ---------------------------------------------------------------------------
+// rad pre-pass: one block per slab, one thread per (clamped) footprint pixel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rad_kernel(FrameParams P, int by0, float *__restrict__ rad)
+{
+    __shared__ float red[256];
+    const int bx = blockIdx.x, by = by0 + blockIdx.y;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    int x = bx * kSlab + tx - 1, y = by * kSlab + ty - 1;                 // kernel.cu:294-295
+    x = max(slab_lo(bx), min(x, slab_up(bx, P.W) - 1));                   // :307-308
+    y = max(slab_lo(by), min(y, slab_up(by, P.H) - 1));
+    f3 front, back;
+    ray_endpoints(P, x, y, front, back);
+    float cl = vlen3(front.x - P.cam_pos[0], front.y - P.cam_pos[1], front.z - P.cam_pos[2]);  // :323-325
+    red[threadIdx.x] = cl;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rad[by * P.nbx + bx] = red[0];
+}
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void stage_tf(float4 *lds_tf, const float4 *__restrict__ tf)
+{
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) lds_tf[i] = tf[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t pack_rgba(float r, float g, float b, float a)
+{
+    // kernel.cu:359-365: clamp to [0,1], * 0xff, truncate
+    uint32_t R = (uint32_t)(fmaxf(0.f, fminf(r, 1.f)) * 255.0f);
+    uint32_t G = (uint32_t)(fmaxf(0.f, fminf(g, 1.f)) * 255.0f);
+    uint32_t B = (uint32_t)(fmaxf(0.f, fminf(b, 1.f)) * 255.0f);
+    uint32_t A = (uint32_t)(fmaxf(0.f, fminf(a, 1.f)) * 255.0f);
+    return R | (G << 8) | (B << 16) | (A << 24);
+}
+
+__device__ __forceinline__ void mark_bricks(uint32_t *bm, const VolumeView &V, float px, float py, float pz)
+{
+    // instrumentation only: 8^3-voxel bricks touched by the 2x2x2 footprint of a sample
+    float xb = fminf(fmaxf(px * (float)V.nx - 0.5f, 0.f), (float)(V.nx - 1));
+    float yb = fminf(fmaxf(py * (float)V.ny - 0.5f, 0.f), (float)(V.ny - 1));
+    float zb = fminf(fmaxf(pz * (float)V.nz - 0.5f, 0.f), (float)(V.nz - 1));
+    int ix = (int)xb, iy = (int)yb, iz = (int)zb;
+    int bnx = (V.nx + 7) >> 3, bny = (V.ny + 7) >> 3;
+    for (int c = 0; c < 8; c++) {
+        int x = min(ix + (c & 1), V.nx - 1) >> 3, y = min(iy + ((c >> 1) & 1), V.ny - 1) >> 3,
+            z = min(iz + (c >> 2), V.nz - 1) >> 3;
+        size_t b = ((size_t)z * bny + y) * bnx + x;
+        uint32_t bit = 1u << (b & 31);
+        if (!(bm[b >> 5] & bit)) atomicOr(&bm[b >> 5], bit);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// march_kernel: no Phong.  blockDim = 256 = 4 waves; each wave owns an 8x8 tile,
+// the block a 16x16 tile.  Grid covers pixel rows [y_begin, y_end).
+// ---------------------------------------------------------------------------
+template <int SLICE, int VOXEL, bool TEX8, bool GRAY, bool INSTR>
+__global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
+                                                    const float4 *__restrict__ tf,
+                                                    const float *__restrict__ rad,
+                                                    uint32_t *__restrict__ pixels,
+                                                    unsigned long long *__restrict__ counter,
+                                                    uint32_t *__restrict__ bricks)
+{
+    __shared__ float4 lds_tf[256];
+    stage_tf(lds_tf, tf);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = P.y_begin + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    // pixels the reference never writes: column W-1 / row H-1 (W,H >= 2)
+    const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax_excl = P.y_end;
+    const bool in_frame = x <= xmax && y < ymax_excl;
+
+    float res_r = 0.f, res_g = 0.f, res_b = 0.f, res_a = 0.f;
+    unsigned long long executed = 0;
+    bool write_zero = false;
+
+    Ray r;
+    int alive = 0;
+    if (in_frame) {
+        f3 front, back;
+        ray_endpoints(P, x, y, front, back);
+        float length = vlen3(back.x - front.x, back.y - front.y, back.z - front.z);
+        if (length < 0.001f) {
+            write_zero = true;                                       // kernel.cu:334-338
+        } else {
+            float rd;
+            if (P.W < 2 || P.H < 2) {      // degenerate footprint: blockMin scans nothing (kernel.cu:89)
+                rd = vlen3(front.x - P.cam_pos[0], front.y - P.cam_pos[1], front.z - P.cam_pos[2]);
+            } else {
+                int ox = owner_slab(x, P.W, P.nbx, P.conflict_x), oy = owner_slab(y, P.H, P.nby, P.conflict_y);
+                rd = rad[oy * P.nbx + ox];
+            }
+            setup_ray(P, front, back, rd, r);
+            alive = r.cut_return ? 0 : 1;
+        }
+    }
+    if (!alive) { r.upper = -1.f; r.dist0 = 0.f; r.sstep = 1.f; r.origin = mk3(0, 0, 0); r.dir = r.origin; r.sdir = r.origin; }
+
+    float dist = r.dist0;
+    bool ert = false;
+    const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
+    const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
+
+    // chunk loop: kernel.cu:248-278.  All lanes of the wave walk chunks together;
+    // a lane whose own `while (dist < upper)` has ended simply has n == 0.
+    for (int chunk = 0; chunk < P.max_chunks && __any(dist < r.upper); ++chunk) {
+        int n = chunk_count(dist, r.upper, r.sstep);
+        if (ert) n = min(n, 1);          // reference ERT: later chunks composite sample 1 only
+        float px, py, pz;
+        {
+#pragma clang fp contract(off)
+            px = r.origin.x + r.dir.x * dist;                        // :249
+            py = r.origin.y + r.dir.y * dist;
+            pz = r.origin.z + r.dir.z * dist;
+        }
+        for (int i = 1; i <= 30; ++i) {
+            px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;          // :141 (sample i = i increments)
+            bool live = i <= n;
+            if (!__any(live)) break;
+            // (pos - .5) / scale + .5 ; scale == 1 is exact in this form   :136
+            float tx = (px - 0.5f) * P.inv_scale[0] + 0.5f;
+            float ty = (py - 0.5f) * P.inv_scale[1] + 0.5f;
+            float tz = (pz - 0.5f) * P.inv_scale[2] + 0.5f;
+            uint32_t idx = sample_index<VOXEL, TEX8>(V, tx, ty, tz);
+            float cr, cg, cb, ca;
+            if (GRAY) {
+                float2 e = *(const float2 *)((const char *)lds_tf + idx * 16 + 8);   // (b, a); r == g == b
+                cr = cg = cb = e.x; ca = e.y;
+            } else {
+                float4 e = lds_tf[idx];
+                cr = e.x; cg = e.y; cb = e.z; ca = e.w;
+            }
+            if (SLICE == SLICE_PLANE) {                                              // :193-198
+#pragma clang fp contract(off)
+                float vd = (float)i * r.sstep + dist;                                // :254
+                float vx = r.origin.x + r.dir.x * vd, vy = r.origin.y + r.dir.y * vd, vz = r.origin.z + r.dir.z * vd;
+                float d = fabsf(sn.x * (vx - sp.x) + sn.y * (vy - sp.y) + sn.z * (vz - sp.z));
+                if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
+            }
+            if (INSTR) {
+                if (live) {
+                    executed++;
+                    if (bricks && bounds_check(tx, ty, tz)) mark_bricks(bricks, V, tx, ty, tz);
+                }
+            }
+            if (live && ca > kEps) {                                                 // :268-270, blend :107-118
+#pragma clang fp contract(off)
+                float bf = ca * (1.f - res_a);
+                res_r = res_r + cr * bf;
+                if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
+                res_a = res_a + bf;
+            }
+            if (live && res_a > P.ert_thr) {                                         // :272-274
+                ert = true; n = 0;
+                if (P.ert_true) r.upper = -1.f;
+            }
+        }
+        {
+#pragma clang fp contract(off)
+            dist += r.sstep * kChunkSteps;                                           // :277
+        }
+    }
+
+    if (in_frame) {
+        if (GRAY) { res_g = res_r; res_b = res_r; }
+        pixels[(size_t)y * P.W + x] = write_zero ? 0u : pack_rgba(res_r, res_g, res_b, res_a);
+    }
+    if (INSTR) {
+        for (int o = 32; o > 0; o >>= 1) executed += __shfl_down(executed, o);
+        if (lane == 0 && executed) atomicAdd(counter, executed);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// march_phong_kernel: one block per reference slab (14x14 interior + apron),
+// 32-deep byte cache in LDS exactly as kernel.cu:125-145 lays it out, but indexed
+// by thread (so clamped apron threads own private entries with identical content).
+// Neighbour look-ups clamp to the slab footprint (DESIGN.md pin 6) and every
+// thread keeps marching its own chunk sequence until the whole block is done, so
+// neighbour entries are never stale (pin 5).
+// ---------------------------------------------------------------------------
+template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
+__global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeView V,
+                                                          const float4 *__restrict__ tf, int by0,
+                                                          uint32_t *__restrict__ pixels,
+                                                          unsigned long long *__restrict__ counter,
+                                                          uint32_t *__restrict__ bricks)
+{
+    __shared__ float4 lds_tf[256];
+    __shared__ float red[256];
+    __shared__ uint8_t cache[kCacheDepth][256];
+    __shared__ int any_live;
+    stage_tf(lds_tf, tf);
+
+    const int bx = blockIdx.x, by = by0 + blockIdx.y;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int lox = slab_lo(bx), upx = slab_up(bx, P.W), loy = slab_lo(by), upy = slab_up(by, P.H);
+    const bool degenerate = (upx - lox) <= 0 || (upy - loy) <= 0;
+    int x = bx * kSlab + tx - 1, y = by * kSlab + ty - 1;
+    x = max(lox, min(x, upx - 1)); y = max(loy, min(y, upy - 1));
+    const bool border = tx == 0 || ty == 0 || tx == 15 || ty == 15;              // kernel.cu:304-305
+
+    f3 front, back;
+    ray_endpoints(P, x, y, front, back);
+    float cl = vlen3(front.x - P.cam_pos[0], front.y - P.cam_pos[1], front.z - P.cam_pos[2]);
+    red[threadIdx.x] = cl;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    float rd = degenerate ? cl : red[0];
+    float length = vlen3(back.x - front.x, back.y - front.y, back.z - front.z);
+    const bool skip = length < 0.001f && !border;                                 // :334
+    Ray r;
+    setup_ray(P, front, back, rd, r);
+
+    // write ownership (pin 10) and one writer per pixel
+    const int ox = owner_slab(x, P.W, P.nbx, P.conflict_x), oy = owner_slab(y, P.H, P.nby, P.conflict_y);
+    bool writer = !border && ox == bx && oy == by;
+    // among interior threads clamped onto the same pixel keep the one whose unclamped
+    // coordinate equals the pixel, or (pin 10 case: none does) the first interior one
+    {
+        int ux = bx * kSlab + tx - 1, uy = by * kSlab + ty - 1;
+        bool xrep = (ux == x) || (bx * kSlab > x && tx == 1);
+        bool yrep = (uy == y) || (by * kSlab > y && ty == 1);
+        writer = writer && xrep && yrep;
+    }
+    // neighbour thread indices, clamped to the footprint
+    int nl, nr, nt, nb;
+    if (degenerate) { nl = nr = nt = nb = threadIdx.x; }
+    else {
+        int xl = max(lox, min(x - 1, upx - 1)), xr = max(lox, min(x + 1, upx - 1));
+        int yt = max(loy, min(y + 1, upy - 1)), yb = max(loy, min(y - 1, upy - 1));
+        int fx0 = bx * kSlab - 1, fy0 = by * kSlab - 1;
+        nl = (y - fy0) * 16 + (xl - fx0); nr = (y - fy0) * 16 + (xr - fx0);
+        nt = (yt - fy0) * 16 + (x - fx0); nb = (yb - fy0) * 16 + (x - fx0);
+    }
+
+    float res_r = 0.f, res_g = 0.f, res_b = 0.f, res_a = 0.f;
+    unsigned long long executed = 0;
+    float dist = r.dist0;
+    bool ert_done = false;
+    const bool marching = writer && !skip && !r.cut_return;
+    const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
+    const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
+
+    for (int chunk = 0; chunk < P.max_chunks; ++chunk) {
+        bool mine = marching && !ert_done && dist < r.upper;
+        if (threadIdx.x == 0) any_live = 0;
+        __syncthreads();
+        if (mine) any_live = 1;
+        __syncthreads();
+        if (!any_live) break;
+        // rayMarch: every thread refreshes its 32 cache entries for this chunk  :125-145
+        {
+            float px, py, pz;
+            {
+#pragma clang fp contract(off)
+                px = r.origin.x + r.dir.x * dist; py = r.origin.y + r.dir.y * dist; pz = r.origin.z + r.dir.z * dist;
+            }
+            for (int i = 0; i < kCacheDepth; ++i) {
+                float tx_ = (px - 0.5f) * P.inv_scale[0] + 0.5f;
+                float ty_ = (py - 0.5f) * P.inv_scale[1] + 0.5f;
+                float tz_ = (pz - 0.5f) * P.inv_scale[2] + 0.5f;
+                cache[i][threadIdx.x] = (uint8_t)sample_index<VOXEL, TEX8>(V, tx_, ty_, tz_);
+                if (INSTR && bricks && mine && i >= 1 && i <= 30 && bounds_check(tx_, ty_, tz_)) mark_bricks(bricks, V, tx_, ty_, tz_);
+                px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;
+            }
+        }
+        __syncthreads();
+        if (mine) {
+            for (int i = 1; i < kCacheDepth - 1; ++i) {
+#pragma clang fp contract(off)
+                float vd = (float)i * r.sstep + dist;                                 // :254
+                if (vd > r.upper) break;
+                if (INSTR) executed++;
+                uint32_t s = cache[i][threadIdx.x];
+                float4 e = lds_tf[s];
+                float cr = e.x, cg = e.y, cb = e.z, ca = e.w;
+                if (ca > kEps) {                                                      // :164 (phong is on)
+                    float f = cache[i - 1][threadIdx.x] / 255.f, a = cache[i + 1][threadIdx.x] / 255.f;
+                    float l = cache[i][nl] / 255.f, rr = cache[i][nr] / 255.f;
+                    float t = cache[i][nt] / 255.f, b = cache[i][nb] / 255.f;
+                    float gx = (rr - l) / (P.tan_fov_x * vd), gy = (t - b) / (P.tan_fov_y * vd),
+                          gz = (a - f) / (r.sstep * 2.f);                             // :175-178, :259-263
+                    if (gx != 0.f && gy != 0.f && gz != 0.f) {
+                        float inv = 1.0f / __fsqrt_rn(gx * gx + gy * gy + gz * gz);
+                        gx *= inv; gy *= inv; gz *= inv;
+                    }
+                    float direct = (gx * -1.f + gy * -1.f + gz * 1.f) * 0.3f;         // :183
+                    direct = fmaxf(0.f, fminf(direct, 0.3f));
+                    cr = cr * 0.7f + direct; cg = cg * 0.7f + direct; cb = cb * 0.7f + direct;
+                }
+                if (SLICE == SLICE_PLANE) {
+                    float vx = r.origin.x + r.dir.x * vd, vy = r.origin.y + r.dir.y * vd, vz = r.origin.z + r.dir.z * vd;
+                    float d = fabsf(sn.x * (vx - sp.x) + sn.y * (vy - sp.y) + sn.z * (vz - sp.z));
+                    if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
+                }
+                if (ca > kEps) {
+                    float bf = ca * (1.f - res_a);
+                    res_r = res_r + cr * bf; res_g = res_g + cg * bf; res_b = res_b + cb * bf; res_a = res_a + bf;
+                }
+                if (res_a > P.ert_thr) { if (P.ert_true) ert_done = true; break; }
+            }
+        }
+        {
+#pragma clang fp contract(off)
+            dist += r.sstep * kChunkSteps;
+        }
+        __syncthreads();      // cache is rewritten next iteration
+    }
+
+    if (writer && y >= P.y_begin && y < P.y_end)
+        pixels[(size_t)y * P.W + x] = skip ? 0u : pack_rgba(res_r, res_g, res_b, res_a);
+    if (INSTR) {
+        for (int o = 32; o > 0; o >>= 1) executed += __shfl_down(executed, o);
+        if ((threadIdx.x & 63) == 0 && executed) atomicAdd(counter, executed);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+template <int SLICE, int VOXEL, bool TEX8, bool GRAY, bool INSTR>
+static void launch_march(const MarchArgs &a, hipStream_t s)
+{
+    dim3 grid((a.P.W + 15) / 16, (a.P.y_end - a.P.y_begin + 15) / 16);
+    hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR>), grid, dim3(256), 0, s,
+                       a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks);
+}
+template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
+static void launch_phong(const MarchArgs &a, hipStream_t s)
+{
+    dim3 grid(a.P.nbx, a.slab_row_end - a.slab_row_begin);
+    hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), 0, s,
+                       a.P, a.V, a.tf, a.slab_row_begin, a.pixels, a.counter, a.bricks);
+}
+
+template <int SLICE, int VOXEL, bool TEX8>
+static void dispatch3(const MarchArgs &a, hipStream_t s)
+{
+    if (a.phong) {
+        if (a.instr) launch_phong<SLICE, VOXEL, TEX8, true>(a, s); else launch_phong<SLICE, VOXEL, TEX8, false>(a, s);
+        return;
+    }
+    const bool gray = a.gray && SLICE != SLICE_PLANE;
+    if (gray) { if (a.instr) launch_march<SLICE, VOXEL, TEX8, true, true>(a, s); else launch_march<SLICE, VOXEL, TEX8, true, false>(a, s); }
+    else      { if (a.instr) launch_march<SLICE, VOXEL, TEX8, false, true>(a, s); else launch_march<SLICE, VOXEL, TEX8, false, false>(a, s); }
+}
+template <int SLICE>
+static void dispatch2(const MarchArgs &a, hipStream_t s)
+{
+    if (a.V_type == VV_VOXEL_F32) { if (a.tex8) dispatch3<SLICE, VV_VOXEL_F32, true>(a, s); else dispatch3<SLICE, VV_VOXEL_F32, false>(a, s); }
+    else                          { if (a.tex8) dispatch3<SLICE, VV_VOXEL_U8,  true>(a, s); else dispatch3<SLICE, VV_VOXEL_U8,  false>(a, s); }
+}
+
+void launch_rad(const MarchArgs &a, hipStream_t s)
+{
+    dim3 grid(a.P.nbx, a.slab_row_end - a.slab_row_begin);
+    hipLaunchKernelGGL(rad_kernel, grid, dim3(256), 0, s, a.P, a.slab_row_begin, a.rad_out);
+}
+
+void launch_raymarch(const MarchArgs &a, hipStream_t s)
+{
+    switch (a.P.slice_type) {                       // kernel.cu:429-447
+    case SLICE_PLANE:     dispatch2<SLICE_PLANE>(a, s); break;
+    case SLICE_PLANE_CUT: dispatch2<SLICE_PLANE_CUT>(a, s); break;
+    default:              dispatch2<SLICE_NONE>(a, s); break;
+    }
+}
+
+} // namespace vv

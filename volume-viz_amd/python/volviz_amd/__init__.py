@@ -1,0 +1,340 @@
+"""ctypes binding of the C-ABI in include/volviz.h (libvolviz_hip.so).
+
+This is the host-side mirror used by tests/, bench.py and __graft_entry__.py.  It is a
+thin 1:1 wrapper: every method names the C entry point it calls, which in turn cites
+the reference interface it replaces (kernel.cuh / volumegenerator.h).  There is no
+Python or CPU implementation of any kernel here -- if the shared library or a HIP
+device is missing, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))          # volume-viz_amd/
+REPO_ROOT = os.path.normpath(os.path.join(PKG_ROOT, ".."))
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libvolviz_hip.so")
+
+# kernel.cuh:18-20
+SLICE_NONE, SLICE_PLANE, SLICE_PLANE_CUT = -1, 0, 1
+# params.h:46
+HORIZONTAL, SAGITTAL, CORONAL, FREE_FORM = 0, 1, 2, 4
+VOXEL_U8, VOXEL_F32 = 0, 1
+FILTER_TEX8, FILTER_EXACT = 0, 1
+ERT_REFERENCE, ERT_TRUE = 0, 1
+RAYS_IMAGES, RAYS_ANALYTIC = 0, 1
+TF_ENGINE, TF_HEAD, TF_MRI = 0, 1, 2
+
+
+class slice_params(C.Structure):          # kernel.cuh:26-29
+    _fields_ = [("type", C.c_int), ("params", C.c_float * 6)]
+
+
+class camera_params(C.Structure):         # kernel.cuh:31-35
+    _fields_ = [("origin", C.c_float * 3), ("fovX", C.c_float), ("fovY", C.c_float),
+                ("scale", C.c_float * 3)]
+
+
+class shading_params(C.Structure):        # kernel.cuh:37-40
+    _fields_ = [("transferPreset", C.c_int), ("phongShading", C.c_bool)]
+
+
+class vv_ray_source(C.Structure):
+    _fields_ = [("mode", C.c_int), ("front", C.c_void_p), ("back", C.c_void_p),
+                ("img_w", C.c_int), ("img_h", C.c_int), ("images_on_device", C.c_int),
+                ("look", C.c_float * 3), ("up", C.c_float * 3), ("aspect", C.c_float),
+                ("quantize8", C.c_int)]
+
+
+class vv_render_options(C.Structure):
+    _fields_ = [("step", C.c_float * 3), ("ert_threshold", C.c_float), ("filter", C.c_int),
+                ("ert_mode", C.c_int), ("slab_row_begin", C.c_int), ("slab_row_end", C.c_int),
+                ("count_samples", C.c_int), ("touched_bricks", C.c_void_p)]
+
+
+EXPORTS = [
+    "vv_init", "vv_shutdown", "vv_last_error", "vv_load_volume_u8", "vv_load_volume_f32",
+    "vv_load_volume_device", "vv_set_transfer_function", "vv_render", "vv_slice",
+    "vv_slice_advanced", "vv_generate_ellipsoids", "vv_generate_default_brain",
+    "vv_promote_u8_to_f32", "vv_generate_noise_u8", "vv_transfer_preset",
+    "vv_t3d_read_header", "vv_t3d_read", "vv_t3d_write", "vv_last_frame_ms",
+    "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix",
+]
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libvolviz_hip.so and declare the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not found: build it with `make -C {PKG_ROOT}` "
+                           "(python __graft_entry__.py does). There is no fallback path.")
+    lib = C.CDLL(p)
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    lib.vv_init.argtypes = [i, C.POINTER(vp)]
+    lib.vv_shutdown.argtypes = [vp]
+    lib.vv_last_error.argtypes = [vp]; lib.vv_last_error.restype = C.c_char_p
+    lib.vv_load_volume_u8.argtypes = [vp, vp, sz, i, i, i, vp]
+    lib.vv_load_volume_f32.argtypes = [vp, vp, sz, i, i, i, vp]
+    lib.vv_load_volume_device.argtypes = [vp, vp, i, i, i, i, vp, vp]
+    lib.vv_set_transfer_function.argtypes = [vp, vp]
+    lib.vv_render.argtypes = [vp, i, i, C.POINTER(slice_params), C.POINTER(camera_params),
+                              C.POINTER(shading_params), C.POINTER(vv_ray_source),
+                              C.POINTER(vv_render_options), vp, i, vp]
+    lib.vv_slice.argtypes = [vp, vp, sz, sz, f, f, f, i, C.POINTER(f * 3), i, i, i, vp]
+    lib.vv_slice_advanced.argtypes = [vp, vp, sz, sz, C.POINTER(f * 16), C.POINTER(f * 3), i, i, vp]
+    lib.vv_generate_ellipsoids.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp, vp]
+    lib.vv_generate_default_brain.argtypes = [vp, vp, i, i, i, i, vp]
+    lib.vv_promote_u8_to_f32.argtypes = [vp, vp, vp, sz, vp]
+    lib.vv_generate_noise_u8.argtypes = [vp, vp, i, i, i, C.c_uint32, vp]
+    lib.vv_transfer_preset.argtypes = [i, vp]
+    lib.vv_t3d_read_header.argtypes = [C.c_char_p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    lib.vv_t3d_read.argtypes = [C.c_char_p, i, vp, sz]
+    lib.vv_t3d_write.argtypes = [C.c_char_p, i, vp, i, i, i]
+    lib.vv_last_frame_ms.argtypes = [vp]; lib.vv_last_frame_ms.restype = f
+    lib.vv_last_sample_count.argtypes = [vp]; lib.vv_last_sample_count.restype = C.c_ulonglong
+    lib.vv_slice_matrix.argtypes = [f, f, f, f, f, f, vp]
+    lib.vv_volume_dims.argtypes = [vp, C.POINTER(i * 3), C.POINTER(i)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("vv_last_error", "vv_last_frame_ms", "vv_last_sample_count"):
+            fn.restype = i
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class VolvizError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"volviz error {code}: {msg}")
+        self.code = code
+
+
+def transfer_preset(preset: int) -> np.ndarray:
+    """vv_transfer_preset: transfer_functions.h:4-9 tables as float32[1024]."""
+    tf = np.zeros(1024, np.float32)
+    rc = load_library().vv_transfer_preset(preset, tf.ctypes.data)
+    if rc:
+        raise VolvizError(rc, "bad preset")
+    return tf
+
+
+@dataclass
+class Camera:
+    """The camera surface of glwidget.cpp:113-114,262-276,338-341 + camera.cpp."""
+    origin: Sequence[float] = (0.0, 0.0, -4.0)
+    look_at: Sequence[float] = (0.0, 0.0, 0.0)
+    up: Sequence[float] = (0.0, 1.0, 0.0)
+    fov_y: float = 45.0
+    scale: Sequence[float] = (1.0, 1.0, 1.0)
+
+    def params(self, width: int, height: int) -> camera_params:
+        aspect = np.float32(width) / np.float32(height)
+        cp = camera_params()
+        cp.origin[:] = [float(v) for v in self.origin]
+        cp.fovY = float(self.fov_y)
+        cp.fovX = float(np.float32(self.fov_y) * aspect)        # glwidget.cpp:341
+        cp.scale[:] = [float(v) for v in self.scale]
+        return cp
+
+    def look(self):
+        return [float(np.float32(t) - np.float32(o)) for t, o in zip(self.look_at, self.origin)]
+
+    @staticmethod
+    def orbit(r: float, theta: float, phi: float, **kw) -> "Camera":
+        """glwidget.cpp:435-445 orbit position."""
+        return Camera(origin=(r * np.sin(theta) * np.cos(phi), r * np.cos(theta),
+                              r * np.sin(theta) * np.sin(phi)), **kw)
+
+
+def analytic_rays(cam: Camera, quantize8: bool = False, aspect: float = 0.0) -> vv_ray_source:
+    rs = vv_ray_source()
+    rs.mode = RAYS_ANALYTIC
+    rs.look[:] = cam.look()
+    rs.up[:] = [float(v) for v in cam.up]
+    rs.aspect = aspect
+    rs.quantize8 = int(quantize8)
+    return rs
+
+
+def image_rays(front: np.ndarray, back: np.ndarray) -> vv_ray_source:
+    """front/back: uint8 [H_fbo, W_fbo, 4] host arrays (kept alive by the caller)."""
+    assert front.dtype == np.uint8 and back.dtype == np.uint8 and front.shape == back.shape
+    rs = vv_ray_source()
+    rs.mode = RAYS_IMAGES
+    rs.front = front.ctypes.data
+    rs.back = back.ctypes.data
+    rs.img_h, rs.img_w = front.shape[0], front.shape[1]
+    rs.images_on_device = 0
+    return rs
+
+
+def make_slice_params(slice_type: int = SLICE_NONE, point=(0.5, 0.5, 0.5), normal=(0.0, 0.0, 1.0)) -> slice_params:
+    sp = slice_params()
+    sp.type = slice_type
+    sp.params[:] = [float(v) for v in (*point, *normal)]
+    return sp
+
+
+def make_options(step=None, ert_threshold=0.0, filter=FILTER_TEX8, ert_mode=ERT_REFERENCE,
+                 slab_rows=(0, 0), count_samples=False, touched_bricks=0) -> vv_render_options:
+    o = vv_render_options()
+    if step is not None:
+        s = [step] * 3 if np.isscalar(step) else list(step)
+        o.step[:] = [float(v) for v in s]
+    o.ert_threshold = ert_threshold
+    o.filter = filter
+    o.ert_mode = ert_mode
+    o.slab_row_begin, o.slab_row_end = slab_rows
+    o.count_samples = int(count_samples)
+    o.touched_bricks = touched_bricks
+    return o
+
+
+class Context:
+    """One vv_context: one device, one volume, one transfer function (kernel.cu:35-51)."""
+
+    def __init__(self, device: int = -1):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.vv_init(device, C.byref(h))
+        if rc:
+            raise VolvizError(rc, (self.lib.vv_last_error(None) or b"").decode())
+        self.h = h
+
+    def _chk(self, rc: int):
+        if rc:
+            raise VolvizError(rc, (self.lib.vv_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.vv_shutdown(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # cudaLoadVolume (kernel.cu:456-498)
+    def load_volume(self, vol: np.ndarray, tf: np.ndarray):
+        """vol: [nz, ny, nx] uint8 or float32 (x fastest); tf: float32[1024]."""
+        assert vol.ndim == 3 and vol.flags.c_contiguous
+        tf = np.ascontiguousarray(tf, np.float32).reshape(1024)
+        nz, ny, nx = vol.shape
+        if vol.dtype == np.uint8:
+            self._chk(self.lib.vv_load_volume_u8(self.h, vol.ctypes.data, vol.nbytes, nx, ny, nz, tf.ctypes.data))
+        elif vol.dtype == np.float32:
+            self._chk(self.lib.vv_load_volume_f32(self.h, vol.ctypes.data, vol.nbytes, nx, ny, nz, tf.ctypes.data))
+        else:
+            raise TypeError("volume must be uint8 or float32")
+
+    def load_volume_device(self, dev_ptr: int, voxel_type: int, nx: int, ny: int, nz: int, tf: np.ndarray, stream: int = 0):
+        tf = np.ascontiguousarray(tf, np.float32).reshape(1024)
+        self._chk(self.lib.vv_load_volume_device(self.h, dev_ptr, voxel_type, nx, ny, nz, tf.ctypes.data, stream))
+
+    def set_transfer_function(self, tf: np.ndarray):
+        tf = np.ascontiguousarray(tf, np.float32).reshape(1024)
+        self._chk(self.lib.vv_set_transfer_function(self.h, tf.ctypes.data))
+
+    # runCuda (kernel.cu:388-453)
+    def render(self, width: int, height: int, cam: Camera, *, slice: Optional[slice_params] = None,
+               phong: bool = False, rays: Optional[vv_ray_source] = None,
+               options: Optional[vv_render_options] = None, out: Optional[np.ndarray] = None,
+               fill: int = 0) -> np.ndarray:
+        """Host-buffer render; returns uint8 [H, W, 4] (row 0 = bottom)."""
+        if out is None:
+            out = np.full((height, width, 4), fill, np.uint8)
+        sp = slice if slice is not None else make_slice_params()
+        cp = cam.params(width, height)
+        sh = shading_params(-1, phong)
+        rs = rays if rays is not None else analytic_rays(cam)
+        self._chk(self.lib.vv_render(self.h, width, height, C.byref(sp), C.byref(cp), C.byref(sh), C.byref(rs),
+                                     C.byref(options) if options is not None else None,
+                                     out.ctypes.data, 0, None))
+        return out
+
+    def render_device(self, width: int, height: int, cam: Camera, out_ptr: int, *, slice=None, phong=False,
+                      rays=None, options=None, stream: int = 0):
+        """Device-buffer render enqueued on `stream` (a hipStream_t as int)."""
+        sp = slice if slice is not None else make_slice_params()
+        cp = cam.params(width, height)
+        sh = shading_params(-1, phong)
+        rs = rays if rays is not None else analytic_rays(cam)
+        self._chk(self.lib.vv_render(self.h, width, height, C.byref(sp), C.byref(cp), C.byref(sh), C.byref(rs),
+                                     C.byref(options) if options is not None else None,
+                                     out_ptr, 1, stream))
+
+    def last_frame_ms(self) -> float:
+        return float(self.lib.vv_last_frame_ms(self.h))
+
+    def last_sample_count(self) -> int:
+        return int(self.lib.vv_last_sample_count(self.h))
+
+    # invoke_slice_kernel (kernel.cu:506-519) / slicekernel.cu legacy
+    def slice(self, height: int, width: int, dx=0.0, dy=0.0, dz=0.0, orientation=SAGITTAL,
+              scale=(1.0, 1.0, 1.0), legacy=False, filter=FILTER_TEX8, fill=0.0) -> np.ndarray:
+        buf = np.full(height * width, fill, np.float32)
+        sc = (C.c_float * 3)(*[float(v) for v in scale])
+        self._chk(self.lib.vv_slice(self.h, buf.ctypes.data, height, width, dx, dy, dz, orientation,
+                                    C.byref(sc), int(legacy), filter, 0, None))
+        return buf
+
+    # invoke_advanced_slice_kernel (kernel.cu:522-541)
+    def slice_advanced(self, height: int, width: int, trans: np.ndarray, scale=(1.0, 1.0, 1.0),
+                       filter=FILTER_TEX8, fill=0.0) -> np.ndarray:
+        buf = np.full(height * width, fill, np.float32)
+        t = (C.c_float * 16)(*[float(v) for v in np.asarray(trans, np.float32).reshape(16)])
+        sc = (C.c_float * 3)(*[float(v) for v in scale])
+        self._chk(self.lib.vv_slice_advanced(self.h, buf.ctypes.data, height, width, C.byref(t), C.byref(sc),
+                                             filter, 0, None))
+        return buf
+
+    # VolumeGenerator::drawEllipsoid x n / drawDefaultBrain (volumegenerator.cpp:31-119)
+    def generate_ellipsoids(self, nx: int, ny: int, nz: int, centers, axes, colors) -> np.ndarray:
+        centers = np.ascontiguousarray(centers, np.float32).reshape(-1, 3)
+        axes = np.ascontiguousarray(axes, np.float32).reshape(-1, 3)
+        colors = np.ascontiguousarray(colors, np.uint8).reshape(-1)
+        out = np.zeros((nz, ny, nx), np.uint8)
+        self._chk(self.lib.vv_generate_ellipsoids(self.h, out.ctypes.data, 0, nx, ny, nz, len(colors),
+                                                  centers.ctypes.data, axes.ctypes.data, colors.ctypes.data, None))
+        return out
+
+    def generate_default_brain(self, nx: int, ny: int, nz: int) -> np.ndarray:
+        out = np.zeros((nz, ny, nx), np.uint8)
+        self._chk(self.lib.vv_generate_default_brain(self.h, out.ctypes.data, 0, nx, ny, nz, None))
+        return out
+
+    def generate_default_brain_device(self, dev_ptr: int, nx: int, ny: int, nz: int, stream: int = 0):
+        self._chk(self.lib.vv_generate_default_brain(self.h, dev_ptr, 1, nx, ny, nz, stream))
+
+    def generate_noise_device(self, dev_ptr: int, nx: int, ny: int, nz: int, seed: int, stream: int = 0):
+        self._chk(self.lib.vv_generate_noise_u8(self.h, dev_ptr, nx, ny, nz, seed, stream))
+
+    def promote_device(self, dev_in: int, dev_out: int, n: int, stream: int = 0):
+        self._chk(self.lib.vv_promote_u8_to_f32(self.h, dev_in, dev_out, n, stream))
+
+
+def slice_matrix(dx, dy, dz, theta, phi, psi) -> np.ndarray:
+    """vv_slice_matrix: SliceWidget::getTransformationMatrix (slicewidget.cpp:147-165)."""
+    m = np.zeros(16, np.float32)
+    rc = load_library().vv_slice_matrix(dx, dy, dz, theta, phi, psi, m.ctypes.data)
+    if rc:
+        raise VolvizError(rc, "angles must be in [-3.2, 3.2)")
+    return m.reshape(4, 4)
