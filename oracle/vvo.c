@@ -178,18 +178,27 @@ static inline uint8_t sat_u8(float f)
     return (uint8_t)(int)f;
 }
 
-/* kernel.cu:99-105 sample(): 0xff * tex3D -> uchar, 0 outside [0,1)^3 */
+/* kernel.cu:99-105 sample(): (uchar)(0xff * tex3D), 0 outside [0,1)^3.
+ * ORACLE PIN 2: for u8 volumes tex3D = L/255 and 0xff * tex3D = L: the normalisation and
+ * the multiplication cancel (255 * RN(k/255) == k for every k in 0..255, so a constant
+ * region classifies exactly), i.e. the index is trunc(L).  f32 volumes: trunc(255 * L). */
 static inline uint8_t sample_u8(const vvo_volume *v, f3 p, int filter)
 {
     if (!bounds_check(p)) return 0;
-    return sat_u8(255.0f * vvo_tex3d(v, p.x, p.y, p.z, filter));
+    float L = tex3d_raw(v, p.x, p.y, p.z, filter);
+    return sat_u8(v->type == VV_VOXEL_U8 ? L : 255.0f * L);
 }
 
-/* kernel.cu:136 (and :585): (pos - .5) / scale + .5 */
-static inline f3 to_tex(f3 p, f3 scale)
+/* kernel.cu:136 (and :585): (pos - .5) / scale + .5.
+ * ORACLE PIN 3: the reference is built with -use_fast_math (hellocudainterop.pro:52), which
+ * turns float division into multiplication by the reciprocal and contracts a*b+c; the
+ * expression is therefore evaluated as fma(pos - .5, 1/scale, .5), 1/scale correctly rounded.
+ * With scale == 1 this equals the literal expression bit for bit. */
+static inline f3 inv3(f3 s) { return mk3(1.0f / s.x, 1.0f / s.y, 1.0f / s.z); }
+static inline f3 to_tex(f3 p, f3 inv_scale)
 {
-    return mk3((p.x - 0.5f) / scale.x + 0.5f, (p.y - 0.5f) / scale.y + 0.5f,
-               (p.z - 0.5f) / scale.z + 0.5f);
+    return mk3(fmaf(p.x - 0.5f, inv_scale.x, 0.5f), fmaf(p.y - 0.5f, inv_scale.y, 0.5f),
+               fmaf(p.z - 0.5f, inv_scale.z, 0.5f));
 }
 
 /* ============================================================================
@@ -200,7 +209,7 @@ void vvo_slice(const vvo_volume *v, float *buffer, size_t height, size_t width,
                float dx, float dy, float dz, int orientation, const float scale[3],
                int legacy, int filter)
 {
-    f3 sc = mk3(scale[0], scale[1], scale[2]);
+    f3 sc = inv3(mk3(scale[0], scale[1], scale[2]));
     for (size_t j = 0; j < height; j++) {
         for (size_t i = 0; i < width; i++) {
             size_t offset = j * height + i;                 /* kernel.cu:550 (height as stride) */
@@ -247,8 +256,9 @@ void vvo_slice_advanced(const vvo_volume *v, float *buffer, size_t height, size_
             p.x = t[0] * rx + t[1] * ry + t[2]  * rz + t[3]  * rw;   /* :616-618, row-major */
             p.y = t[4] * rx + t[5] * ry + t[6]  * rz + t[7]  * rw;
             p.z = t[8] * rx + t[9] * ry + t[10] * rz + t[11] * rw;
-            p.x /= scale[0]; p.y /= scale[1]; p.z /= scale[2];       /* :620-622 */
-            p = to_tex(p, mk3(scale[0], scale[1], scale[2]));        /* :624 (second scale) */
+            f3 inv = inv3(mk3(scale[0], scale[1], scale[2]));
+            p.x *= inv.x; p.y *= inv.y; p.z *= inv.z;                /* :620-622 (pin 3: reciprocal) */
+            p = to_tex(p, inv);                                      /* :624 (second scale) */
             buffer[offset] = bounds_check(p) ? vvo_tex3d(v, p.x, p.y, p.z, filter) : 0.f;
         }
     }
@@ -420,7 +430,7 @@ typedef struct {
 
 typedef struct {
     const vvo_volume *vol; const float *tf;
-    int W, H; int slice_type; f3 slice_point, slice_normal, scale, step, cam_pos;
+    int W, H; int slice_type; f3 slice_point, slice_normal, scale, inv_scale, step, cam_pos;
     float tan_fov_x, tan_fov_y; int phong; int filter; int ert_true; float ert_thr;
     const vv_ray_source *rays; const struct camera_params *cam;
 } frame_t;
@@ -468,7 +478,7 @@ static void ray_march(const frame_t *F, const ray_t *r, float dist, uint8_t out[
 {
     f3 pos = add3(r->origin, scl3(r->dir, dist));                       /* :249 */
     for (int i = 0; i < CACHE_DEPTH; i++) {
-        out[i] = sample_u8(F->vol, to_tex(pos, F->scale), F->filter);   /* :136 */
+        out[i] = sample_u8(F->vol, to_tex(pos, F->inv_scale), F->filter);   /* :136 */
         pos = add3(pos, r->sdir);                                       /* :141 */
     }
 }
@@ -649,6 +659,7 @@ unsigned long long vvo_render(const vvo_volume *v, const float tf[1024], int W, 
     F.slice_point  = mk3(slice->params[0], slice->params[1], slice->params[2]);   /* kernel.cu:224 */
     F.slice_normal = mk3(slice->params[3], slice->params[4], slice->params[5]);   /* :225 */
     F.scale = mk3(cam->scale[0], cam->scale[1], cam->scale[2]);                  /* :226 */
+    F.inv_scale = inv3(F.scale);
     F.cam_pos = mk3(cam->origin[0], cam->origin[1], cam->origin[2]);             /* :323 */
     F.step = mk3(1.f / (float)v->nx, 1.f / (float)v->ny, 1.f / (float)v->nz);    /* :415 */
     F.filter = VV_FILTER_TEX8; F.ert_true = 0; F.ert_thr = .95f;

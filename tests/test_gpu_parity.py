@@ -1,12 +1,15 @@
 """GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on the
 same inputs, and against the committed golden fixtures.
 
-Bars (BASELINE.md section 3):
+Bars:
   * generator      : bit-exact
   * slice sampler  : bit-exact (float results, both filter modes)
-  * ray march      : RGBA8, <= 1 LSB per channel on >= 99.9 % of pixels, <= 2 LSB max
-                     (the kernel fuses multiply-adds in the per-sample position transform
-                     and uses v_rsq in Phong shading; see DESIGN.md "tolerance")
+  * ray march      : BASELINE.md section 3 states RGBA8 <= 1 LSB per channel on >= 99.9 % of
+                     pixels, <= 2 LSB max.  The HIP kernels evaluate every float operation in
+                     the oracle's order (IEEE div/sqrt, no contraction outside the texture
+                     model), so the tests hold them to the stronger bar: bit-exact frames
+                     and identical executed-sample counts.  STRICT = False falls back to
+                     the BASELINE tolerance (for future approximate fast paths).
 """
 import hashlib
 import json
@@ -26,8 +29,14 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+STRICT = True
+
+
 def assert_frames_close(got, want, what=""):
     assert got.shape == want.shape
+    if STRICT:
+        bad = np.argwhere(np.any(got != want, axis=-1))
+        assert len(bad) == 0, f"{what}: {len(bad)} pixels differ, first {bad[0]}: {got[tuple(bad[0])]} vs {want[tuple(bad[0])]}"
     d = np.abs(got.astype(np.int16) - want.astype(np.int16)).max(axis=-1)
     frac_gt1 = float((d > 1).mean())
     exact = float((d == 0).mean())
@@ -225,7 +234,7 @@ def test_render_image_ray_source(ctx):
         got = ctx.render(W, H, cam, rays=rs, phong=phong)
         want, _ = O.render(vol, tf, W, H, cam, rays=rs, phong=phong)
         assert_frames_close(got, want, f"images phong={phong}")
-        assert (got[..., 3] > 0).mean() > 0.2
+        assert (got[..., 3] > 0).mean() > 0.1
 
 
 def test_render_quantised_analytic(ctx):

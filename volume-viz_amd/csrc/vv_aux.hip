@@ -22,7 +22,11 @@ __global__ __launch_bounds__(256) void slice_kernel(SliceArgs A)
     if (!(j < A.height && i < A.width)) return;                   // kernel.cu:552
     const size_t offset = j * A.height + i;                       // kernel.cu:550,604 (height as stride)
     if (offset >= A.height * A.width) return;                     // the reference would write out of bounds
+    // width > height: (j,i) and (j+1,i-height) share an offset (a write race in the
+    // reference).  Pinned like the oracle's loop order: the larger j wins.
+    if (i >= A.height && j + 1 < A.height) return;
     const float u = ((float)i) / ((float)A.width), w = ((float)j) / ((float)A.height);
+    const float ix = 1.0f / A.scale[0], iy = 1.0f / A.scale[1], iz = 1.0f / A.scale[2];
     float px, py, pz;
     bool check = true;
     if (A.advanced) {
@@ -30,10 +34,10 @@ __global__ __launch_bounds__(256) void slice_kernel(SliceArgs A)
         px = A.trans[0] * u + A.trans[1] * w + A.trans[2]  * rz + A.trans[3]  * rw;
         py = A.trans[4] * u + A.trans[5] * w + A.trans[6]  * rz + A.trans[7]  * rw;
         pz = A.trans[8] * u + A.trans[9] * w + A.trans[10] * rz + A.trans[11] * rw;
-        px /= A.scale[0]; py /= A.scale[1]; pz /= A.scale[2];     // :620-622
-        px = (px - 0.5f) / A.scale[0] + 0.5f;                     // :624 (scaled a second time)
-        py = (py - 0.5f) / A.scale[1] + 0.5f;
-        pz = (pz - 0.5f) / A.scale[2] + 0.5f;
+        px *= ix; py *= iy; pz *= iz;                             // :620-622 (reciprocal, DESIGN.md pin 3)
+        px = __builtin_fmaf(px - 0.5f, ix, 0.5f);                 // :624 (scaled a second time)
+        py = __builtin_fmaf(py - 0.5f, iy, 0.5f);
+        pz = __builtin_fmaf(pz - 0.5f, iz, 0.5f);
     } else {
         px = 0.f; py = 0.f; pz = 0.f;
         if (A.legacy) { px = u; py = w; pz = 0.f; }               // slicekernel.cu:62-64
@@ -46,9 +50,9 @@ __global__ __launch_bounds__(256) void slice_kernel(SliceArgs A)
         px += A.dx; py += A.dy; pz += A.dz;                       // :581-583
         if (A.legacy) check = false;                              // slicekernel.cu:70: unconditional fetch
         else {
-            px = (px - 0.5f) / A.scale[0] + 0.5f;                 // :585
-            py = (py - 0.5f) / A.scale[1] + 0.5f;
-            pz = (pz - 0.5f) / A.scale[2] + 0.5f;
+            px = __builtin_fmaf(px - 0.5f, ix, 0.5f);             // :585
+            py = __builtin_fmaf(py - 0.5f, iy, 0.5f);
+            pz = __builtin_fmaf(pz - 0.5f, iz, 0.5f);
         }
     }
     float s = 0.f;

@@ -67,7 +67,7 @@ struct FrameParams {
 __device__ __forceinline__ float vlen3(float x, float y, float z)
 {
 #pragma clang fp contract(off)
-    return __fsqrt_rn(x * x + y * y + z * z);       // kernel.cu:53-57
+    return sqrtf(x * x + y * y + z * z);       // kernel.cu:53-57
 }
 __device__ __forceinline__ float dot3s(f3 a, f3 b)
 {
@@ -151,7 +151,7 @@ __device__ __forceinline__ void setup_ray(const FrameParams &P, f3 front, f3 bac
         float c = dot3s(l0p0, l0p0) - rad * rad;
         float disc = b * b - c;
         if (disc >= 0.f) {
-            float t = b * -1.f - __fsqrt_rn(disc);
+            float t = b * -1.f - sqrtf(disc);
             if (t >= -kEps) pos = mk3(pos.x - ray.x * t, pos.y - ray.y * t, pos.z - ray.z * t);  // :347
         }
     }
@@ -275,10 +275,9 @@ __device__ __forceinline__ bool bounds_check(float x, float y, float z)
     return m < 0x3F800000u;
 }
 
-// kernel.cu:99-105 sample(): (uchar)(0xff * tex3D) or 0 outside.  For u8 volumes
-// 255 * (L/255) truncates to trunc(L) except when L is within 1 ulp below an
-// integer (p ~ 1e-5 per sample), so the classification index is
-// taken from L directly.
+// kernel.cu:99-105 sample(): (uchar)(0xff * tex3D) or 0 outside.  For u8 volumes the
+// normalisation and the multiplication cancel, the index is trunc(L) (DESIGN.md pin 2);
+// f32 volumes: trunc(255 * L), saturated.
 template <int VOXEL, bool TEX8>
 __device__ __forceinline__ uint32_t sample_index(const VolumeView &V, float px, float py, float pz)
 {

@@ -145,10 +145,10 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
             px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;          // :141 (sample i = i increments)
             bool live = i <= n;
             if (!__any(live)) break;
-            // (pos - .5) / scale + .5 ; scale == 1 is exact in this form   :136
-            float tx = (px - 0.5f) * P.inv_scale[0] + 0.5f;
-            float ty = (py - 0.5f) * P.inv_scale[1] + 0.5f;
-            float tz = (pz - 0.5f) * P.inv_scale[2] + 0.5f;
+            // (pos - .5) / scale + .5 as fma(pos - .5, 1/scale, .5)   :136, DESIGN.md pin 3
+            float tx = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
+            float ty = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
+            float tz = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
             uint32_t idx = sample_index<VOXEL, TEX8>(V, tx, ty, tz);
             float cr, cg, cb, ca;
             if (GRAY) {
@@ -288,9 +288,9 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
                 px = r.origin.x + r.dir.x * dist; py = r.origin.y + r.dir.y * dist; pz = r.origin.z + r.dir.z * dist;
             }
             for (int i = 0; i < kCacheDepth; ++i) {
-                float tx_ = (px - 0.5f) * P.inv_scale[0] + 0.5f;
-                float ty_ = (py - 0.5f) * P.inv_scale[1] + 0.5f;
-                float tz_ = (pz - 0.5f) * P.inv_scale[2] + 0.5f;
+                float tx_ = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
+                float ty_ = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
+                float tz_ = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
                 cache[i][threadIdx.x] = (uint8_t)sample_index<VOXEL, TEX8>(V, tx_, ty_, tz_);
                 if (INSTR && bricks && mine && i >= 1 && i <= 30 && bounds_check(tx_, ty_, tz_)) mark_bricks(bricks, V, tx_, ty_, tz_);
                 px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
                     float gx = (rr - l) / (P.tan_fov_x * vd), gy = (t - b) / (P.tan_fov_y * vd),
                           gz = (a - f) / (r.sstep * 2.f);                             // :175-178, :259-263
                     if (gx != 0.f && gy != 0.f && gz != 0.f) {
-                        float inv = 1.0f / __fsqrt_rn(gx * gx + gy * gy + gz * gz);
+                        float inv = 1.0f / sqrtf(gx * gx + gy * gy + gz * gz);
                         gx *= inv; gy *= inv; gz *= inv;
                     }
                     float direct = (gx * -1.f + gy * -1.f + gz * 1.f) * 0.3f;         // :183
