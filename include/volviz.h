@@ -122,8 +122,16 @@ typedef struct vv_render_options {
     float    ert_threshold;  /* 0 => .95f (kernel.cu:272)                        */
     int      filter;         /* vv_filter                                        */
     int      ert_mode;       /* vv_ert_mode                                      */
-    int      slab_row_begin; /* render only 14-pixel slab rows [begin,end) of    */
-    int      slab_row_end;   /* the global slab grid; 0,0 => all (multi-GPU shard)*/
+    /* Screen-tile sharding (multi-GPU).  A pixel row y belongs to slab row r = y/14 of the
+     * global 14x14 slab grid (kernel.cu:418); this call renders the rows whose r satisfies
+     *   begin <= r < end   (0,0 => all)   and   (r / shard_band) % shard_count == shard_index
+     * Other rows are left untouched.  shard_count <= 1 disables the interleave;
+     * shard_band must be a multiple of 4 slab rows when shard_count > 1.              */
+    int      slab_row_begin;
+    int      slab_row_end;
+    int      shard_band;     /* slab rows per interleave band (e.g. 4 = 56 pixel rows)  */
+    int      shard_count;    /* number of shards (ranks)                                */
+    int      shard_index;    /* this shard                                               */
     int      count_samples;  /* 1 => count executed samples (vv_last_sample_count)*/
     uint32_t *touched_bricks;/* device bitmap, 1 bit per 8^3 brick, or NULL:     */
                              /* instrumentation for the roofline's byte model    */

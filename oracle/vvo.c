@@ -433,6 +433,7 @@ typedef struct {
     int W, H; int slice_type; f3 slice_point, slice_normal, scale, inv_scale, step, cam_pos;
     float tan_fov_x, tan_fov_y; int phong; int filter; int ert_true; float ert_thr;
     const vv_ray_source *rays; const struct camera_params *cam;
+    int rb, re, band, count, index;   /* slab-row shard predicate, include/volviz.h */
 } frame_t;
 
 /* kernel.cu:107-118 blend */
@@ -603,6 +604,10 @@ static unsigned long long render_block(const frame_t *F, int bx, int by, uint8_t
         int ox = (W >= 2 && W - 1 == (nbx - 1) * (BLOCK_W - 2) && px[t] == W - 2) ? nbx - 1 : px[t] / (BLOCK_W - 2);
         int oy = (H >= 2 && H - 1 == (nby - 1) * (BLOCK_W - 2) && py[t] == H - 2) ? nby - 1 : py[t] / (BLOCK_W - 2);
         if (ox != bx || oy != by) continue;
+        {   /* shard predicate on the pixel row's geometric slab row (include/volviz.h) */
+            int r = py[t] / (BLOCK_W - 2);
+            if (!(r >= F->rb && r < F->re && ((r / F->band) % F->count) == F->index)) continue;
+        }
         int key = (py[t] - (by * (BLOCK_W - 2) - 1)) * BLOCK_W + (px[t] - (bx * (BLOCK_W - 2) - 1));
         if (seen[key]) continue;
         seen[key] = 1;
@@ -664,7 +669,9 @@ unsigned long long vvo_render(const vvo_volume *v, const float tf[1024], int W, 
     F.step = mk3(1.f / (float)v->nx, 1.f / (float)v->ny, 1.f / (float)v->nz);    /* :415 */
     F.filter = VV_FILTER_TEX8; F.ert_true = 0; F.ert_thr = .95f;
     int rb = 0, re = 0;
+    F.band = 4; F.count = 1; F.index = 0;
     if (opts) {
+        if (opts->shard_count > 1) { F.count = opts->shard_count; F.index = opts->shard_index; F.band = opts->shard_band; }
         if (opts->step[0] > 0.f || opts->step[1] > 0.f || opts->step[2] > 0.f)
             F.step = mk3(opts->step[0], opts->step[1], opts->step[2]);
         if (opts->ert_threshold > 0.f) F.ert_thr = opts->ert_threshold;
@@ -681,6 +688,7 @@ unsigned long long vvo_render(const vvo_volume *v, const float tf[1024], int W, 
     int nby = H / (BLOCK_W - 2) + ((H % (BLOCK_W - 2)) ? 1 : 0);
     if (rb == 0 && re == 0) re = nby;
     if (re > nby) re = nby;
+    F.rb = rb; F.re = re;
     unsigned long long executed = 0;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
@@ -690,7 +698,7 @@ unsigned long long vvo_render(const vvo_volume *v, const float tf[1024], int W, 
 #ifdef _OPENMP
     #pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+:executed)
 #endif
-    for (long b = (long)rb * nbx; b < (long)re * nbx; b++)
+    for (long b = 0; b < (long)nby * nbx; b++)
         executed += render_block(&F, (int)(b % nbx), (int)(b / nbx), rgba);
     return executed;
 }

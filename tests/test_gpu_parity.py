@@ -286,6 +286,33 @@ def test_render_sharded_rows_reassemble(ctx):
         assert np.array_equal(parts, full)
 
 
+@pytest.mark.parametrize("W,H", [(60, 130), (45, 43), (33, 200), (1280, 720)])
+def test_render_interleaved_shards(ctx, W, H):
+    """The multi-GPU split: bands of 4 slab rows dealt round-robin to `count` shards."""
+    vol = O.draw_default_brain(24, 24, 24)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    cam = vv.Camera.orbit(4.0, 1.0, 0.6)
+    for phong in (False, True):
+        full = ctx.render(W, H, cam, phong=phong, fill=1, options=vv.make_options(count_samples=True))
+        n = ctx.last_sample_count()
+        for count in (2, 8):
+            parts = np.full_like(full, 1)
+            total = 0
+            for idx in range(count):
+                only = np.full_like(full, 1)
+                ctx.render(W, H, cam, phong=phong, options=vv.make_options(shard=(4, count, idx), count_samples=True), out=only)
+                total += ctx.last_sample_count()
+                rows = np.array([((y // 14) // 4) % count == idx for y in range(H)])
+                assert np.all(only[~rows] == 1)
+                parts[rows] = only[rows]
+            assert np.array_equal(parts, full) and total == n
+        if H <= 200:
+            want, _ = O.render(vol, tf, W, H, cam, phong=phong, fill=1, options=vv.make_options(shard=(4, 3, 1)))
+            got = ctx.render(W, H, cam, phong=phong, fill=1, options=vv.make_options(shard=(4, 3, 1)))
+            assert_frames_close(got, want)
+
+
 def test_render_full_size_properties(ctx):
     """BASELINE config C2 size (256^3 f32, 1280x720): size-independent properties instead of
     a full oracle frame -- (1) a 3-slab-row band of the oracle matches, (2) the frame equals the

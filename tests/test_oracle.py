@@ -208,6 +208,28 @@ def test_slab_row_sharding_reassembles():
     assert np.array_equal(parts, full) and total == n
 
 
+@pytest.mark.parametrize("W,H", [(60, 130), (45, 43), (33, 200)])
+def test_interleaved_shards_reassemble(W, H):
+    """(r / band) % count == index sharding (the multi-GPU screen-tile split)."""
+    vol = O.draw_default_brain(24, 24, 24)
+    tf = O.transfer_preset(vv.TF_ENGINE)
+    cam = vv.Camera.orbit(4.0, 1.0, 0.6)
+    for phong in (False, True):
+        full, n = O.render(vol, tf, W, H, cam, phong=phong, fill=1)
+        for count in (2, 3):
+            parts = np.full_like(full, 1)
+            total = 0
+            for idx in range(count):
+                only = np.full_like(full, 1)
+                _, k = O.render(vol, tf, W, H, cam, phong=phong, options=vv.make_options(shard=(4, count, idx)), out=only)
+                total += k
+                rows = [y for y in range(H) if ((y // 14) // 4) % count == idx]
+                other = [y for y in range(H) if y not in rows]
+                assert np.all(only[other] == 1)            # nothing outside the shard is touched
+                parts[rows] = only[rows]
+            assert np.array_equal(parts, full) and total == n
+
+
 def test_oracle_frames_are_stable(golden_dir):
     """Regression pin: the oracle still produces the committed frames."""
     g = np.load(os.path.join(golden_dir, "frames_oracle.npz"))

@@ -44,7 +44,9 @@ struct FrameParams {
     int W, H;
     int nbx, nby;                 // slab grid, kernel.cu:418-425
     int conflict_x, conflict_y;   // W-1 == 14*(nbx-1) (resp. H): last block re-writes a pixel
-    int y_begin, y_end;           // pixel rows rendered by this call (slab-row shard)
+    // slab-row shard predicate (include/volviz.h vv_render_options): a pixel row y is rendered
+    // iff r = y/14 satisfies  rb <= r < re  &&  (r / band) % count == index
+    int rb, re, band, count, index;
     int slice_type;
     float slice_point[3], slice_normal[3];
     float cam_pos[3], scale[3], inv_scale[3];
@@ -127,6 +129,12 @@ __device__ __host__ __forceinline__ int slab_up(int b, int n) { int v = (b + 1) 
 __device__ __host__ __forceinline__ int owner_slab(int p, int n, int nb, int conflict)
 {
     return (conflict && p == n - 2) ? nb - 1 : p / kSlab;
+}
+
+__device__ __host__ __forceinline__ bool row_owned(const FrameParams &P, int y)
+{
+    int r = y / kSlab;
+    return r >= P.rb && r < P.re && ((r / P.band) % P.count) == P.index;
 }
 
 struct Ray {

@@ -5,12 +5,17 @@
 
 namespace vv {
 
+// blockIdx.y -> pixel strip (march_kernel) / slab row (march_phong_kernel) of a shard
+struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips; };
+struct SlabMap  { int r0, band, band_stride, n_regular; };
+
 struct MarchArgs {
     FrameParams P;
     VolumeView  V;
     int V_type;                 // vv_voxel_type
     bool tex8, gray, phong, instr;
-    int slab_row_begin, slab_row_end;
+    StripMap strips;                   // march_kernel: strips of 8 pixel rows (n_strips of them)
+    SlabMap slabs;                     // march_phong_kernel grid.y = n_regular + 1
     const float4 *tf;           // device, 256 entries
     const float *rad;           // device, nbx*nby (read by march_kernel)
     float *rad_out;             // same buffer (written by rad_kernel)

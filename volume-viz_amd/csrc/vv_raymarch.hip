@@ -20,10 +20,10 @@ namespace vv {
 // ---------------------------------------------------------------------------
 // rad pre-pass: one block per slab, one thread per (clamped) footprint pixel.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rad_kernel(FrameParams P, int by0, float *__restrict__ rad)
+__global__ __launch_bounds__(256) void rad_kernel(FrameParams P, float *__restrict__ rad)
 {
     __shared__ float red[256];
-    const int bx = blockIdx.x, by = by0 + blockIdx.y;
+    const int bx = blockIdx.x, by = blockIdx.y;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     int x = bx * kSlab + tx - 1, y = by * kSlab + ty - 1;                 // kernel.cu:294-295
     x = max(slab_lo(bx), min(x, slab_up(bx, P.W) - 1));                   // :307-308
@@ -46,6 +46,16 @@ __global__ __launch_bounds__(256) void rad_kernel(FrameParams P, int by0, float 
 __device__ __forceinline__ void stage_tf(float4 *lds_tf, const float4 *__restrict__ tf)
 {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) lds_tf[i] = tf[i];
+    __syncthreads();
+}
+// Channel-planar copy of the table: entry idx of channel c sits in LDS bank idx % 32, so the
+// data-dependent look-up of a wave spreads over all banks (the float4 layout hits 8 of 32).
+__device__ __forceinline__ void stage_tf_planar(float *lds_tf, const float4 *__restrict__ tf)
+{
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        float4 e = tf[i];
+        lds_tf[i] = e.x; lds_tf[256 + i] = e.y; lds_tf[512 + i] = e.z; lds_tf[768 + i] = e.w;
+    }
     __syncthreads();
 }
 
@@ -77,8 +87,10 @@ __device__ __forceinline__ void mark_bricks(uint32_t *bm, const VolumeView &V, f
 }
 
 // ---------------------------------------------------------------------------
-// march_kernel: no Phong.  blockDim = 256 = 4 waves; each wave owns an 8x8 tile,
-// the block a 16x16 tile.  Grid covers pixel rows [y_begin, y_end).
+// march_kernel: no Phong.  blockDim = 256 = 4 waves; a block owns a 32x8 pixel strip, each
+// wave a 2^tw x 2^(6-tw) tile of it (32x2 when screen x runs along the volume's x axis, so
+// that the lanes of a gather walk one memory row; 8x8 otherwise).  blockIdx.x enumerates
+// (strip, tile) pairs of the shard (StripMap).
 // ---------------------------------------------------------------------------
 template <int SLICE, int VOXEL, bool TEX8, bool GRAY, bool INSTR>
 __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
@@ -86,17 +98,24 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                                                     const float *__restrict__ rad,
                                                     uint32_t *__restrict__ pixels,
                                                     unsigned long long *__restrict__ counter,
-                                                    uint32_t *__restrict__ bricks)
+                                                    uint32_t *__restrict__ bricks, StripMap M)
 {
-    __shared__ float4 lds_tf[256];
-    stage_tf(lds_tf, tf);
+    __shared__ float lds_tf[1024];
 
+    const int ntx = (P.W + 31) >> 5;
+    const int strip = blockIdx.x / ntx, tile_x = blockIdx.x % ntx;
+    if (strip >= M.n_strips) return;                       // block-uniform, before any barrier
+    stage_tf_planar(lds_tf, tf);
+
+    // wave tile = 2^tw x 2^(6-tw) pixels; the 4 waves of a block tile a 32x8 strip
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = P.y_begin + blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int tw = M.tile_log2w, th = 6 - tw;
+    const int wx = wave & ((32 >> tw) - 1), wy = wave >> (5 - tw);
+    const int x = (tile_x << 5) + (wx << tw) + (lane & ((1 << tw) - 1));
+    const int y = M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * 8 + (wy << th) + (lane >> tw);
     // pixels the reference never writes: column W-1 / row H-1 (W,H >= 2)
-    const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax_excl = P.y_end;
-    const bool in_frame = x <= xmax && y < ymax_excl;
+    const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax = P.H >= 2 ? P.H - 2 : 0;
+    const bool in_frame = x <= xmax && y <= ymax && row_owned(P, y);
 
     float res_r = 0.f, res_g = 0.f, res_b = 0.f, res_a = 0.f;
     unsigned long long executed = 0;
@@ -141,46 +160,56 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
             py = r.origin.y + r.dir.y * dist;
             pz = r.origin.z + r.dir.z * dist;
         }
-        for (int i = 1; i <= 30; ++i) {
-            px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;          // :141 (sample i = i increments)
-            bool live = i <= n;
-            if (!__any(live)) break;
-            // (pos - .5) / scale + .5 as fma(pos - .5, 1/scale, .5)   :136, DESIGN.md pin 3
-            float tx = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
-            float ty = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
-            float tz = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-            uint32_t idx = sample_index<VOXEL, TEX8>(V, tx, ty, tz);
-            float cr, cg, cb, ca;
-            if (GRAY) {
-                float2 e = *(const float2 *)((const char *)lds_tf + idx * 16 + 8);   // (b, a); r == g == b
-                cr = cg = cb = e.x; ca = e.y;
-            } else {
-                float4 e = lds_tf[idx];
-                cr = e.x; cg = e.y; cb = e.z; ca = e.w;
+        // U samples per trip (all U gathers issued before the first is consumed).  Measured on
+        // MI355X, C3: U = 2 is not faster (the kernel is bandwidth-, not latency-bound) and
+        // costs a wave of occupancy, so U = 1.
+        constexpr int U = 1;
+        for (int i0 = 1; i0 <= 30; i0 += U) {
+            if (!__any(i0 <= n)) break;
+            float tx[U], ty[U], tz[U];
+            uint32_t idx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;      // :141 (sample i = i increments)
+                // (pos - .5) / scale + .5 as fma(pos - .5, 1/scale, .5)   :136, DESIGN.md pin 3
+                tx[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
+                ty[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
+                tz[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
+                idx[u] = sample_index<VOXEL, TEX8>(V, tx[u], ty[u], tz[u]);
             }
-            if (SLICE == SLICE_PLANE) {                                              // :193-198
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u;
+                const bool live = i <= n;
+                float cr, cg, cb, ca;
+                ca = lds_tf[768 + idx[u]];
+                cr = lds_tf[idx[u]];
+                if (GRAY) { cg = cb = cr; }                      // r == g == b
+                else { cg = lds_tf[256 + idx[u]]; cb = lds_tf[512 + idx[u]]; }
+                if (SLICE == SLICE_PLANE) {                                              // :193-198
 #pragma clang fp contract(off)
-                float vd = (float)i * r.sstep + dist;                                // :254
-                float vx = r.origin.x + r.dir.x * vd, vy = r.origin.y + r.dir.y * vd, vz = r.origin.z + r.dir.z * vd;
-                float d = fabsf(sn.x * (vx - sp.x) + sn.y * (vy - sp.y) + sn.z * (vz - sp.z));
-                if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
-            }
-            if (INSTR) {
-                if (live) {
-                    executed++;
-                    if (bricks && bounds_check(tx, ty, tz)) mark_bricks(bricks, V, tx, ty, tz);
+                    float vd = (float)i * r.sstep + dist;                                // :254
+                    float vx = r.origin.x + r.dir.x * vd, vy = r.origin.y + r.dir.y * vd, vz = r.origin.z + r.dir.z * vd;
+                    float d = fabsf(sn.x * (vx - sp.x) + sn.y * (vy - sp.y) + sn.z * (vz - sp.z));
+                    if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
                 }
-            }
-            if (live && ca > kEps) {                                                 // :268-270, blend :107-118
+                if (INSTR) {
+                    if (live) {
+                        executed++;
+                        if (bricks && bounds_check(tx[u], ty[u], tz[u])) mark_bricks(bricks, V, tx[u], ty[u], tz[u]);
+                    }
+                }
+                if (live && ca > kEps) {                                                 // :268-270, blend :107-118
 #pragma clang fp contract(off)
-                float bf = ca * (1.f - res_a);
-                res_r = res_r + cr * bf;
-                if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
-                res_a = res_a + bf;
-            }
-            if (live && res_a > P.ert_thr) {                                         // :272-274
-                ert = true; n = 0;
-                if (P.ert_true) r.upper = -1.f;
+                    float bf = ca * (1.f - res_a);
+                    res_r = res_r + cr * bf;
+                    if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
+                    res_a = res_a + bf;
+                }
+                if (live && res_a > P.ert_thr) {                                         // :272-274
+                    ert = true; n = 0;
+                    if (P.ert_true) r.upper = -1.f;
+                }
             }
         }
         {
@@ -209,7 +238,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 // ---------------------------------------------------------------------------
 template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeView V,
-                                                          const float4 *__restrict__ tf, int by0,
+                                                          const float4 *__restrict__ tf, SlabMap M,
                                                           uint32_t *__restrict__ pixels,
                                                           unsigned long long *__restrict__ counter,
                                                           uint32_t *__restrict__ bricks)
@@ -220,7 +249,19 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
     __shared__ int any_live;
     stage_tf(lds_tf, tf);
 
-    const int bx = blockIdx.x, by = by0 + blockIdx.y;
+    // blockIdx.y -> slab row of this shard; the last grid row is the "extra" slab row
+    // nby-1 that re-writes pixel row H-2 when H == 1 (mod 14) (pin 10): it travels with
+    // the shard that owns pixel row H-2.
+    const int bx = blockIdx.x;
+    int by;
+    if ((int)blockIdx.y == M.n_regular) { if (!P.conflict_y) return; by = P.nby - 1; }
+    else by = M.r0 + ((int)blockIdx.y / M.band) * M.band_stride + ((int)blockIdx.y % M.band);
+    if (by >= P.nby) return;                                   // block-uniform
+    {
+        // ownership is decided on the pixel rows this slab row writes
+        int yrow = (P.conflict_y && by == P.nby - 1) ? P.H - 2 : by * kSlab;
+        if (yrow > (P.H >= 2 ? P.H - 2 : 0) || !row_owned(P, yrow)) return;   // block-uniform
+    }
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int lox = slab_lo(bx), upx = slab_up(bx, P.W), loy = slab_lo(by), upy = slab_up(by, P.H);
     const bool degenerate = (upx - lox) <= 0 || (upy - loy) <= 0;
@@ -339,7 +380,7 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
         __syncthreads();      // cache is rewritten next iteration
     }
 
-    if (writer && y >= P.y_begin && y < P.y_end)
+    if (writer)
         pixels[(size_t)y * P.W + x] = skip ? 0u : pack_rgba(res_r, res_g, res_b, res_a);
     if (INSTR) {
         for (int o = 32; o > 0; o >>= 1) executed += __shfl_down(executed, o);
@@ -353,16 +394,17 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
 template <int SLICE, int VOXEL, bool TEX8, bool GRAY, bool INSTR>
 static void launch_march(const MarchArgs &a, hipStream_t s)
 {
-    dim3 grid((a.P.W + 15) / 16, (a.P.y_end - a.P.y_begin + 15) / 16);
+    const int ntx = (a.P.W + 31) / 32;
+    dim3 grid((unsigned)(a.strips.n_strips * ntx));
     hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR>), grid, dim3(256), 0, s,
-                       a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks);
+                       a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
 }
 template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 static void launch_phong(const MarchArgs &a, hipStream_t s)
 {
-    dim3 grid(a.P.nbx, a.slab_row_end - a.slab_row_begin);
+    dim3 grid(a.P.nbx, a.slabs.n_regular + 1);
     hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), 0, s,
-                       a.P, a.V, a.tf, a.slab_row_begin, a.pixels, a.counter, a.bricks);
+                       a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
 }
 
 template <int SLICE, int VOXEL, bool TEX8>
@@ -385,8 +427,10 @@ static void dispatch2(const MarchArgs &a, hipStream_t s)
 
 void launch_rad(const MarchArgs &a, hipStream_t s)
 {
-    dim3 grid(a.P.nbx, a.slab_row_end - a.slab_row_begin);
-    hipLaunchKernelGGL(rad_kernel, grid, dim3(256), 0, s, a.P, a.slab_row_begin, a.rad_out);
+    // every slab of the frame: a shard's pixels may need the radius of any slab row that
+    // intersects its strips, and the whole pass costs about one sample per pixel
+    dim3 grid(a.P.nbx, a.P.nby);
+    hipLaunchKernelGGL(rad_kernel, grid, dim3(256), 0, s, a.P, a.rad_out);
 }
 
 void launch_raymarch(const MarchArgs &a, hipStream_t s)

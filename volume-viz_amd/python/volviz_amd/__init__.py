@@ -54,6 +54,7 @@ class vv_ray_source(C.Structure):
 class vv_render_options(C.Structure):
     _fields_ = [("step", C.c_float * 3), ("ert_threshold", C.c_float), ("filter", C.c_int),
                 ("ert_mode", C.c_int), ("slab_row_begin", C.c_int), ("slab_row_end", C.c_int),
+                ("shard_band", C.c_int), ("shard_count", C.c_int), ("shard_index", C.c_int),
                 ("count_samples", C.c_int), ("touched_bricks", C.c_void_p)]
 
 
@@ -186,7 +187,7 @@ def make_slice_params(slice_type: int = SLICE_NONE, point=(0.5, 0.5, 0.5), norma
 
 
 def make_options(step=None, ert_threshold=0.0, filter=FILTER_TEX8, ert_mode=ERT_REFERENCE,
-                 slab_rows=(0, 0), count_samples=False, touched_bricks=0) -> vv_render_options:
+                 slab_rows=(0, 0), shard=None, count_samples=False, touched_bricks=0) -> vv_render_options:
     o = vv_render_options()
     if step is not None:
         s = [step] * 3 if np.isscalar(step) else list(step)
@@ -195,6 +196,8 @@ def make_options(step=None, ert_threshold=0.0, filter=FILTER_TEX8, ert_mode=ERT_
     o.filter = filter
     o.ert_mode = ert_mode
     o.slab_row_begin, o.slab_row_end = slab_rows
+    if shard is not None:                       # (band, count, index)
+        o.shard_band, o.shard_count, o.shard_index = shard
     o.count_samples = int(count_samples)
     o.touched_bricks = touched_bricks
     return o
