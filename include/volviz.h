@@ -195,6 +195,11 @@ int  vv_generate_ellipsoids(vv_context *ctx, uint8_t *out, int out_on_device,
                             int nx, int ny, int nz, int n,
                             const float *centers /* n*3 */, const float *axes /* n*3 */,
                             const uint8_t *colors /* n */, void *stream);
+/* One drawEllipsoid call (volumegenerator.cpp:31-97) applied IN PLACE to an existing volume:
+ * voxels outside the ellipsoid keep their value, the marker slab fi >= 0.99 is set to 4. */
+int  vv_draw_ellipsoid(vv_context *ctx, uint8_t *vol, int vol_on_device,
+                       int nx, int ny, int nz, const float center[3], const float axes[3],
+                       uint8_t color, void *stream);
 int  vv_generate_default_brain(vv_context *ctx, uint8_t *out, int out_on_device,
                                int nx, int ny, int nz, void *stream);
 /* u8 -> f32 promotion v/255 on the device (build extension for f32 configs). */

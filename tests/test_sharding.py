@@ -1,0 +1,66 @@
+"""N > 1 host path on CPU: two gloo ranks each fill their bands of a frame (rendered here by
+the oracle, standing in for the GPU kernel, with the same shard predicate), then run the
+product's gather / re-assembly code (volviz_amd.sharding) exactly as bench.py does."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+import volviz_amd as vv
+from volviz_amd import sharding
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, W, H, phong, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vol = O.draw_default_brain(24, 24, 24)
+    tf = O.transfer_preset(vv.TF_ENGINE)
+    cam = vv.Camera.orbit(4.0, 1.0, 0.6)
+    hp = sharding.padded_height(H, world)
+    frame = np.full((hp, W, 4), 7, np.uint8)
+    O.render(vol, tf, W, H, cam, phong=phong, options=vv.make_options(shard=sharding.shard_option(world, rank)),
+             out=frame[:H])
+    t = torch.from_numpy(frame)
+    out = sharding.gather_frame(t, world, rank)
+    if rank == 0:
+        q.put(out.numpy()[:H].copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("W,H,phong", [(60, 130, False), (45, 43, True)])
+def test_two_rank_gather_reassembles_frame(world, W, H, phong):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, phong, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    vol = O.draw_default_brain(24, 24, 24)
+    want, _ = O.render(vol, O.transfer_preset(vv.TF_ENGINE), W, H, vv.Camera.orbit(4.0, 1.0, 0.6), phong=phong, fill=7)
+    assert np.array_equal(got, want)
+
+
+def test_band_bookkeeping():
+    for H in (1, 14, 56, 57, 1080, 2160):
+        for world in (1, 2, 4, 8):
+            rows = [sharding.owned_rows(H, world, r) for r in range(world)]
+            assert sorted(sum(rows, [])) == list(range(H))
+            assert sharding.padded_height(H, world) % (sharding.BAND_PX * world) == 0
+            assert sharding.padded_height(H, world) >= H
+    f = torch.arange(2 * 56 * 3 * 4, dtype=torch.uint8).reshape(2 * 56, 3, 4)
+    assert torch.equal(sharding.compact(f, 2, 1)[0], f[56:112])

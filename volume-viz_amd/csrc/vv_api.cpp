@@ -423,8 +423,23 @@ int vv_slice_advanced(vv_context *c, float *buffer, size_t height, size_t width,
 }
 
 // ---- generator: VolumeGenerator::drawEllipsoid / drawDefaultBrain ------------------------
+static int generate_impl(vv_context *c, uint8_t *out, int out_on_device, int nx, int ny, int nz, int n,
+                         const float *centers, const float *axes, const uint8_t *colors, int in_place, void *stream);
+
 int vv_generate_ellipsoids(vv_context *c, uint8_t *out, int out_on_device, int nx, int ny, int nz, int n,
                            const float *centers, const float *axes, const uint8_t *colors, void *stream)
+{
+    return generate_impl(c, out, out_on_device, nx, ny, nz, n, centers, axes, colors, 0, stream);
+}
+
+int vv_draw_ellipsoid(vv_context *c, uint8_t *vol, int vol_on_device, int nx, int ny, int nz,
+                      const float center[3], const float axes[3], uint8_t color, void *stream)
+{
+    return generate_impl(c, vol, vol_on_device, nx, ny, nz, 1, center, axes, &color, 1, stream);
+}
+
+static int generate_impl(vv_context *c, uint8_t *out, int out_on_device, int nx, int ny, int nz, int n,
+                         const float *centers, const float *axes, const uint8_t *colors, int in_place, void *stream)
 {
     if (!c) return fail(nullptr, VV_ERR_INVALID, "vv_generate_ellipsoids: NULL context");
     if (!out || nx < 1 || ny < 1 || nz < 1 || n < 0 || n > kMaxEllipsoids || (n > 0 && (!centers || !axes || !colors)))
@@ -434,9 +449,12 @@ int vv_generate_ellipsoids(vv_context *c, uint8_t *out, int out_on_device, int n
     const size_t bytes = (size_t)nx * ny * nz;
     uint8_t *d = out;
     void *tmp = nullptr;
-    if (!out_on_device) { HIPCHK(c, hipMalloc(&tmp, bytes)); d = (uint8_t *)tmp; }
+    if (!out_on_device) {
+        HIPCHK(c, hipMalloc(&tmp, bytes)); d = (uint8_t *)tmp;
+        if (in_place && hipMemcpyAsync(d, out, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { hipFree(tmp); return fail(c, VV_ERR_DEVICE, "vv_draw_ellipsoid: upload failed"); }
+    }
     if (((uintptr_t)d & 15) != 0) { if (tmp) hipFree(tmp); return fail(c, VV_ERR_INVALID, "vv_generate_ellipsoids: device buffer must be 16-byte aligned"); }
-    launch_generate_ellipsoids(d, nx, ny, nz, n, centers, axes, colors, st);
+    launch_generate_ellipsoids(d, nx, ny, nz, n, centers, axes, colors, in_place, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && !out_on_device) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && (!out_on_device || !stream)) e = hipStreamSynchronize(st);

@@ -90,7 +90,7 @@ struct EllipsoidSet {
 // All arithmetic is uncontracted binary32 with IEEE division, as g++ compiles
 // volumegenerator.cpp:44-59, so the output is bit-identical.
 __global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ out, int nx, int ny, int nz,
-                                                        int xchunks, EllipsoidSet E)
+                                                        int xchunks, EllipsoidSet E, int in_place)
 {
 #pragma clang fp contract(off)
     const size_t total = (size_t)xchunks * ny * nz;
@@ -103,6 +103,8 @@ __global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ ou
         uint32_t packed[4] = {0u, 0u, 0u, 0u};
         uint8_t vals[16];
         for (int v = 0; v < 16; ++v) vals[v] = 0;                                   // ctor zero-fill :12-23
+        if (in_place)                                                               // else keep, :60-62
+            for (int v = 0; v < 16 && i0 + v < nx; ++v) vals[v] = out[row * (size_t)nx + i0 + v];
         for (int e = 0; e < E.n; ++e) {
             const float ey = (E.cy[e] - fj) / E.ay[e], ez = (E.cz[e] - fk) / E.az[e];
             const float eyy = ey * ey, ezz = ez * ez;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ ou
 
 void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
                                 const float *centers, const float *axes, const uint8_t *colors,
-                                hipStream_t s)
+                                int in_place, hipStream_t s)
 {
     EllipsoidSet E;
     E.n = n;
@@ -140,7 +142,7 @@ void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(ellipsoid_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, nx, ny, nz, xchunks, E);
+    hipLaunchKernelGGL(ellipsoid_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, nx, ny, nz, xchunks, E, in_place);
 }
 
 // ---------------------------------------------------------------------------

@@ -64,7 +64,7 @@ EXPORTS = [
     "vv_slice_advanced", "vv_generate_ellipsoids", "vv_generate_default_brain",
     "vv_promote_u8_to_f32", "vv_generate_noise_u8", "vv_transfer_preset",
     "vv_t3d_read_header", "vv_t3d_read", "vv_t3d_write", "vv_last_frame_ms",
-    "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix",
+    "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid",
 ]
 
 _lib = None
@@ -95,6 +95,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_slice_advanced.argtypes = [vp, vp, sz, sz, C.POINTER(f * 16), C.POINTER(f * 3), i, i, vp]
     lib.vv_generate_ellipsoids.argtypes = [vp, vp, i, i, i, i, i, vp, vp, vp, vp]
     lib.vv_generate_default_brain.argtypes = [vp, vp, i, i, i, i, vp]
+    lib.vv_draw_ellipsoid.argtypes = [vp, vp, i, i, i, i, vp, vp, C.c_uint8, vp]
     lib.vv_promote_u8_to_f32.argtypes = [vp, vp, vp, sz, vp]
     lib.vv_generate_noise_u8.argtypes = [vp, vp, i, i, i, C.c_uint32, vp]
     lib.vv_transfer_preset.argtypes = [i, vp]
@@ -318,6 +319,15 @@ class Context:
         self._chk(self.lib.vv_generate_ellipsoids(self.h, out.ctypes.data, 0, nx, ny, nz, len(colors),
                                                   centers.ctypes.data, axes.ctypes.data, colors.ctypes.data, None))
         return out
+
+    def draw_ellipsoid(self, vol: np.ndarray, center, axes, color: int) -> np.ndarray:
+        """vv_draw_ellipsoid: one VolumeGenerator::drawEllipsoid applied in place to vol [nz,ny,nx]."""
+        assert vol.dtype == np.uint8 and vol.flags.c_contiguous
+        nz, ny, nx = vol.shape
+        c = np.ascontiguousarray(center, np.float32); a = np.ascontiguousarray(axes, np.float32)
+        self._chk(self.lib.vv_draw_ellipsoid(self.h, vol.ctypes.data, 0, nx, ny, nz, c.ctypes.data, a.ctypes.data,
+                                             int(color), None))
+        return vol
 
     def generate_default_brain(self, nx: int, ny: int, nz: int) -> np.ndarray:
         out = np.zeros((nz, ny, nx), np.uint8)
