@@ -44,7 +44,8 @@ def ramp_tf() -> np.ndarray:
 def workload(args, world):
     if args.config == "c3":
         n = 1024
-        W, H, steps = FRAMES.get(world, (int(1920 * world ** 0.5), int(1080 * world ** 0.5), 512))
+        fw = args.frame_of or world
+        W, H, steps = FRAMES.get(fw, (int(1920 * fw ** 0.5), int(1080 * fw ** 0.5), 512))
     elif args.config == "c2":
         n, (W, H, steps) = 256, (1280, 720, 256)
     else:   # c1 geometry on the GPU (the CPU-runnable case)
@@ -67,6 +68,7 @@ def main():
     ap.add_argument("--voxel", default="f32", choices=["f32", "u8"], help="u8 is a diagnostic variant, not the C3 metric")
     ap.add_argument("--filter", default="tex8", choices=["tex8", "exact"])
     ap.add_argument("--ert", default="reference", choices=["reference", "true"])
+    ap.add_argument("--frame-of", type=int, default=0, help="render the frame/step an N-GPU run would use (check aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -78,10 +80,18 @@ def main():
         sys.exit("launch N > 1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the product has no CPU path")
+    # VV_BENCH_SHARE_GPU=1 (developer rehearsal on a 1-GPU box): every rank uses cuda:0 and the
+    # gather goes through gloo on host copies.  Never used for reported numbers.
+    share = os.environ.get("VV_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n, W, H, steps = workload(args, world)
     ctx = vv.Context(local)
@@ -121,10 +131,19 @@ def main():
     if world > 1 and rank == 0:
         recv = [torch.empty_like(sharding.compact(frame, world, 0)) for _ in range(world)]
 
+    def gather():
+        if not share:
+            return sharding.gather_frame(frame, world, rank, recv)
+        torch.cuda.synchronize()
+        out = sharding.gather_frame(frame.cpu(), world, rank)
+        if rank == 0:
+            frame.copy_(out)
+        return out
+
     def one_frame(o):
         ctx.render_device(W, H, cam, frame.data_ptr(), options=o, stream=stream)
         if world > 1:
-            sharding.gather_frame(frame, world, rank, recv)
+            gather()
 
     # ---- untimed instrumented pass: executed samples + bricks touched (byte model) ----
     nb = (n + BRICK - 1) // BRICK
@@ -133,12 +152,15 @@ def main():
     ctx.render_device(W, H, cam, frame.data_ptr(), options=iopts, stream=stream)
     torch.cuda.synchronize()
     samples = ctx.last_sample_count()
+    if os.environ.get("VV_STATS"):
+        print("stats", ctx.debug_counters().tolist(), file=sys.stderr)
     words = bitmap.cpu().numpy().view(np.uint32)
     bricks = int(np.unpackbits(words.view(np.uint8)).sum())
     rows_owned = len(sharding.owned_rows(H, world, rank))
     vbytes = 4 if args.voxel == "f32" else 1
     bytes_rank = bricks * BRICK ** 3 * vbytes + 4 * W * rows_owned + 4096     # SURVEY 8d B_frame
-    tot = torch.tensor([samples, bytes_rank], dtype=torch.float64, device=dev)
+    rdev = torch.device("cpu") if share else dev
+    tot = torch.tensor([samples, bytes_rank], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tot)
     samples_all, bytes_all = float(tot[0]), float(tot[1])
@@ -156,12 +178,12 @@ def main():
         ctx.render_device(W, H, cam, frame.data_ptr(), options=opts, stream=stream)
         ev[k][1].record()
         if world > 1:
-            sharding.gather_frame(frame, world, rank, recv)
+            gather()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el[0])
@@ -172,6 +194,9 @@ def main():
             dist.destroy_process_group()
         return
 
+    if os.environ.get("VV_BENCH_FRAME_SHA"):
+        import hashlib
+        print("frame_sha", hashlib.sha256(frame[:H].cpu().numpy().tobytes()).hexdigest()[:16], file=sys.stderr)
     ms_per_step = elapsed / args.steps * 1e3
     value = samples_all * args.steps / elapsed / 1e6
     achieved = bytes_rank / (kern_ms * 1e-3)

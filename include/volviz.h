@@ -221,6 +221,7 @@ int  vv_t3d_write(const char *path, int header, const uint8_t *src, int nx, int 
 /* ---- metrics (the reference only has a clock() overlay) ---------------- */
 float              vv_last_frame_ms(const vv_context *ctx);      /* hipEvent time of the last vv_render */
 unsigned long long vv_last_sample_count(vv_context *ctx);        /* executed samples, if count_samples */
+int                vv_debug_counters(vv_context *ctx, unsigned long long out[8]);   /* developer statistics */
 int                vv_volume_dims(const vv_context *ctx, int dims[3], int *voxel_type);
 
 #ifdef __cplusplus

@@ -10,6 +10,7 @@ typedef float __attribute__((ext_vector_type(2))) f2a;
 typedef float __attribute__((ext_vector_type(4))) f4a;
 typedef float __attribute__((ext_vector_type(4), aligned(4))) f4u;
 typedef unsigned short __attribute__((aligned(1))) us_u;
+typedef unsigned __attribute__((aligned(1))) u32_u;
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(const char* __restrict__ buf, int iters, int rowstride, float spacing, int tw, float* out, int footprint)
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(256) void k(const char* __restrict__ buf, int iters
         if (MODE == 5) { acc += (float)*(const us_u*)(base + e); }                                 // u8 pair (ushort)
         if (MODE == 6) { acc += (float)*(const unsigned char*)(base + e); }
         if (MODE == 7) { acc += (float)*(const unsigned*)(base + (e & ~3u)); }                     // aligned dword of u8 (4 voxels)
+        if (MODE == 8) { acc += (float)*(const u32_u*)(base + e); }                                // byte-aligned dword (u8 x..x+3)
         asm volatile("" : "+v"(acc));
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
@@ -40,7 +42,7 @@ int main(int argc, char** argv)
     int footprint = 64 * 1024;
     char* buf; hipMalloc(&buf, 64 * footprint + 4096); hipMemset(buf, 0, 64 * footprint + 4096);
     float* out; hipMalloc(&out, 2048 * 256 * 4);
-    const char* names[] = {"dword", "dwordx2 unaligned", "dwordx2 aligned", "dwordx4 aligned", "dwordx4 unaligned", "ushort", "ubyte", "dword(u8x4) aligned"};
+    const char* names[] = {"dword", "dwordx2 unaligned", "dwordx2 aligned", "dwordx4 aligned", "dwordx4 unaligned", "ushort", "ubyte", "dword(u8x4) aligned", "dword byte-aligned"};
     int iters = 4096, blocks = 2048;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     struct Pat { const char* n; int tw; int rowstride; float spacing; } pats[] = {
@@ -48,7 +50,7 @@ int main(int argc, char** argv)
         {"tile 8x8 s=1.5 rs=160 (LDS-like box)", 3, 160, 1.5f}, {"scattered: 8x8 s=40 rs=1024", 3, 1024, 40.f}};
     for (auto& p : pats) {
         printf("pattern %s\n", p.n);
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < 9; ++m) {
             float ms = 0;
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(a);
@@ -61,6 +63,7 @@ int main(int argc, char** argv)
                 case 5: k<5><<<blocks, 256>>>(buf, iters, p.rowstride, p.spacing, p.tw, out, footprint); break;
                 case 6: k<6><<<blocks, 256>>>(buf, iters, p.rowstride, p.spacing, p.tw, out, footprint); break;
                 case 7: k<7><<<blocks, 256>>>(buf, iters, p.rowstride, p.spacing, p.tw, out, footprint); break;
+                case 8: k<8><<<blocks, 256>>>(buf, iters, p.rowstride, p.spacing, p.tw, out, footprint); break;
                 }
                 hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
             }

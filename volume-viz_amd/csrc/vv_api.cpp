@@ -73,7 +73,7 @@ int vv_init(int device, vv_context **out)
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc((void **)&c->d_counter, sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&c->d_counter, 8 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&c->d_tf, 256 * sizeof(float4)) != hipSuccess) {
         delete c;
         return fail(nullptr, VV_ERR_DEVICE, "vv_init: device set-up failed");
@@ -156,6 +156,16 @@ int vv_load_volume_f32(vv_context *c, const float *texels, size_t size, int nx, 
 int vv_load_volume_device(vv_context *c, const void *dev, int vtype, int nx, int ny, int nz, const float tf[1024], void *stream)
 {
     return install_volume(c, dev, true, vtype, nx, ny, nz, tf, (hipStream_t)stream);
+}
+
+// developer statistics of the last instrumented launch (staged kernel): [0] executed samples,
+// [1] stages, [2] samples served from global memory, [3] bytes staged into LDS, [4] wave compute trips
+int vv_debug_counters(vv_context *c, unsigned long long out[8])
+{
+    if (!c || !out || !c->counter_valid) return VV_ERR_INVALID;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return VV_ERR_DEVICE;
+    if (hipMemcpy(out, c->d_counter, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return VV_ERR_DEVICE;
+    return VV_OK;
 }
 
 int vv_volume_dims(const vv_context *c, int dims[3], int *vtype)
@@ -328,14 +338,19 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     A.pixels = (uint32_t *)d_out;
     if (((uintptr_t)d_out & 3) != 0) return fail(c, VV_ERR_INVALID, "vv_render: output buffer must be 4-byte aligned");
 
-    if (A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter, 0, sizeof(unsigned long long), st));
+    if (A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter, 0, 8 * sizeof(unsigned long long), st));
     c->counter_valid = A.instr;
     HIPCHK(c, hipEventRecord(c->ev0, st));
     if (A.phong) {
         launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
-        launch_raymarch(A, st);
+        // The LDS-staged slab march (vv_raymarch_staged.hip) is bit-identical but, as measured on
+        // MI355X in round 1, slower than the gather kernel (C3: 4.0 ms vs 1.5 ms): opt-in only.
+        // It needs 16-byte aligned volume rows.
+        bool staged = false;
+        if (const char *e = getenv("VV_STAGED")) staged = atoi(e) != 0 && (A.V.row_bytes % 16u) == 0;
+        if (staged) launch_raymarch_staged(A, st); else launch_raymarch(A, st);
     }
     HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, hipGetLastError());

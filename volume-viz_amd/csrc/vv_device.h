@@ -295,4 +295,32 @@ __device__ __forceinline__ uint32_t sample_index(const VolumeView &V, float px, 
     return bounds_check(px, py, pz) ? idx : 0u;
 }
 
+__device__ __forceinline__ uint32_t pack_rgba(float r, float g, float b, float a)
+{
+    // kernel.cu:359-365: clamp to [0,1], * 0xff, truncate
+    uint32_t R = (uint32_t)(fmaxf(0.f, fminf(r, 1.f)) * 255.0f);
+    uint32_t G = (uint32_t)(fmaxf(0.f, fminf(g, 1.f)) * 255.0f);
+    uint32_t B = (uint32_t)(fmaxf(0.f, fminf(b, 1.f)) * 255.0f);
+    uint32_t A = (uint32_t)(fmaxf(0.f, fminf(a, 1.f)) * 255.0f);
+    return R | (G << 8) | (B << 16) | (A << 24);
+}
+
+__device__ __forceinline__ void mark_bricks(uint32_t *bm, const VolumeView &V, float px, float py, float pz)
+{
+    // instrumentation only: 8^3-voxel bricks touched by the 2x2x2 footprint of a sample
+    float xb = fminf(fmaxf(px * (float)V.nx - 0.5f, 0.f), (float)(V.nx - 1));
+    float yb = fminf(fmaxf(py * (float)V.ny - 0.5f, 0.f), (float)(V.ny - 1));
+    float zb = fminf(fmaxf(pz * (float)V.nz - 0.5f, 0.f), (float)(V.nz - 1));
+    int ix = (int)xb, iy = (int)yb, iz = (int)zb;
+    int bnx = (V.nx + 7) >> 3, bny = (V.ny + 7) >> 3;
+    for (int c = 0; c < 8; c++) {
+        int x = min(ix + (c & 1), V.nx - 1) >> 3, y = min(iy + ((c >> 1) & 1), V.ny - 1) >> 3,
+            z = min(iz + (c >> 2), V.nz - 1) >> 3;
+        size_t b = ((size_t)z * bny + y) * bnx + x;
+        uint32_t bit = 1u << (b & 31);
+        if (!(bm[b >> 5] & bit)) atomicOr(&bm[b >> 5], bit);
+    }
+}
+
+
 } // namespace vv

@@ -59,33 +59,6 @@ __device__ __forceinline__ void stage_tf_planar(float *lds_tf, const float4 *__r
     __syncthreads();
 }
 
-__device__ __forceinline__ uint32_t pack_rgba(float r, float g, float b, float a)
-{
-    // kernel.cu:359-365: clamp to [0,1], * 0xff, truncate
-    uint32_t R = (uint32_t)(fmaxf(0.f, fminf(r, 1.f)) * 255.0f);
-    uint32_t G = (uint32_t)(fmaxf(0.f, fminf(g, 1.f)) * 255.0f);
-    uint32_t B = (uint32_t)(fmaxf(0.f, fminf(b, 1.f)) * 255.0f);
-    uint32_t A = (uint32_t)(fmaxf(0.f, fminf(a, 1.f)) * 255.0f);
-    return R | (G << 8) | (B << 16) | (A << 24);
-}
-
-__device__ __forceinline__ void mark_bricks(uint32_t *bm, const VolumeView &V, float px, float py, float pz)
-{
-    // instrumentation only: 8^3-voxel bricks touched by the 2x2x2 footprint of a sample
-    float xb = fminf(fmaxf(px * (float)V.nx - 0.5f, 0.f), (float)(V.nx - 1));
-    float yb = fminf(fmaxf(py * (float)V.ny - 0.5f, 0.f), (float)(V.ny - 1));
-    float zb = fminf(fmaxf(pz * (float)V.nz - 0.5f, 0.f), (float)(V.nz - 1));
-    int ix = (int)xb, iy = (int)yb, iz = (int)zb;
-    int bnx = (V.nx + 7) >> 3, bny = (V.ny + 7) >> 3;
-    for (int c = 0; c < 8; c++) {
-        int x = min(ix + (c & 1), V.nx - 1) >> 3, y = min(iy + ((c >> 1) & 1), V.ny - 1) >> 3,
-            z = min(iz + (c >> 2), V.nz - 1) >> 3;
-        size_t b = ((size_t)z * bny + y) * bnx + x;
-        uint32_t bit = 1u << (b & 31);
-        if (!(bm[b >> 5] & bit)) atomicOr(&bm[b >> 5], bit);
-    }
-}
-
 // ---------------------------------------------------------------------------
 // march_kernel: no Phong.  blockDim = 256 = 4 waves; a block owns a 32x8 pixel strip, each
 // wave a 2^tw x 2^(6-tw) tile of it (32x2 when screen x runs along the volume's x axis, so
@@ -102,17 +75,16 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 {
     __shared__ float lds_tf[1024];
 
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ntx = (P.W + 31) >> 5;
     const int strip = blockIdx.x / ntx, tile_x = blockIdx.x % ntx;
-    if (strip >= M.n_strips) return;                       // block-uniform, before any barrier
-    stage_tf_planar(lds_tf, tf);
-
     // wave tile = 2^tw x 2^(6-tw) pixels; the 4 waves of a block tile a 32x8 strip
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tw = M.tile_log2w, th = 6 - tw;
     const int wx = wave & ((32 >> tw) - 1), wy = wave >> (5 - tw);
     const int x = (tile_x << 5) + (wx << tw) + (lane & ((1 << tw) - 1));
     const int y = M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * 8 + (wy << th) + (lane >> tw);
+    if (strip >= M.n_strips) return;                       // block-uniform, before any barrier
+    stage_tf_planar(lds_tf, tf);
     // pixels the reference never writes: column W-1 / row H-1 (W,H >= 2)
     const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax = P.H >= 2 ? P.H - 2 : 0;
     const bool in_frame = x <= xmax && y <= ymax && row_owned(P, y);

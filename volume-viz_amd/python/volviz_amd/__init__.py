@@ -64,7 +64,7 @@ EXPORTS = [
     "vv_slice_advanced", "vv_generate_ellipsoids", "vv_generate_default_brain",
     "vv_promote_u8_to_f32", "vv_generate_noise_u8", "vv_transfer_preset",
     "vv_t3d_read_header", "vv_t3d_read", "vv_t3d_write", "vv_last_frame_ms",
-    "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid",
+    "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid", "vv_debug_counters",
 ]
 
 _lib = None
@@ -105,6 +105,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_last_frame_ms.argtypes = [vp]; lib.vv_last_frame_ms.restype = f
     lib.vv_last_sample_count.argtypes = [vp]; lib.vv_last_sample_count.restype = C.c_ulonglong
     lib.vv_slice_matrix.argtypes = [f, f, f, f, f, f, vp]
+    lib.vv_debug_counters.argtypes = [vp, vp]
     lib.vv_volume_dims.argtypes = [vp, C.POINTER(i * 3), C.POINTER(i)]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -287,6 +288,11 @@ class Context:
 
     def last_frame_ms(self) -> float:
         return float(self.lib.vv_last_frame_ms(self.h))
+
+    def debug_counters(self):
+        out = np.zeros(8, np.uint64)
+        self._chk(self.lib.vv_debug_counters(self.h, out.ctypes.data))
+        return out
 
     def last_sample_count(self) -> int:
         return int(self.lib.vv_last_sample_count(self.h))
