@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--voxel", default="f32", choices=["f32", "u8"], help="u8 is a diagnostic variant, not the C3 metric")
     ap.add_argument("--filter", default="tex8", choices=["tex8", "exact"])
     ap.add_argument("--ert", default="reference", choices=["reference", "true"])
+    ap.add_argument("--phong", action="store_true", help="Phong-shaded path (diagnostic; C3 is unshaded)")
     ap.add_argument("--frame-of", type=int, default=0, help="render the frame/step an N-GPU run would use (check aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -141,7 +142,7 @@ def main():
         return out
 
     def one_frame(o):
-        ctx.render_device(W, H, cam, frame.data_ptr(), options=o, stream=stream)
+        ctx.render_device(W, H, cam, frame.data_ptr(), options=o, stream=stream, phong=args.phong)
         if world > 1:
             gather()
 
@@ -149,7 +150,7 @@ def main():
     nb = (n + BRICK - 1) // BRICK
     bitmap = torch.zeros((nb * nb * nb + 31) // 32, dtype=torch.int32, device=dev)
     iopts = vv.make_options(count_samples=True, touched_bricks=bitmap.data_ptr(), **base)
-    ctx.render_device(W, H, cam, frame.data_ptr(), options=iopts, stream=stream)
+    ctx.render_device(W, H, cam, frame.data_ptr(), options=iopts, stream=stream, phong=args.phong)
     torch.cuda.synchronize()
     samples = ctx.last_sample_count()
     if os.environ.get("VV_STATS"):
@@ -175,7 +176,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        ctx.render_device(W, H, cam, frame.data_ptr(), options=opts, stream=stream)
+        ctx.render_device(W, H, cam, frame.data_ptr(), options=opts, stream=stream, phong=args.phong)
         ev[k][1].record()
         if world > 1:
             gather()
@@ -213,7 +214,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.voxel, "data": "synthetic",
         "config": {"workload": f"{args.config.upper()}: {n}^3 {args.voxel} {args.volume} volume, {W}x{H}, step 1/{steps}, "
-                               f"{args.tf} RGBA TF, ERT {args.ert}, {args.filter} filter, view {args.view}",
+                               f"{args.tf} RGBA TF, ERT {args.ert}, {args.filter} filter, view {args.view}" + (", Phong" if args.phong else ""),
                    "volume": [n, n, n], "frame": [W, H], "steps_per_unit_length": steps,
                    "sharding": "single GPU" if world == 1 else f"bands of {sharding.BAND_PX} pixel rows round-robin over {world} GPUs, volume replicated, 1 RCCL gather/frame"},
         "executed_samples_per_frame": int(samples_all), "upper_bound_samples_WxHxS": W * H * steps,

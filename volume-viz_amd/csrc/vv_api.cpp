@@ -125,8 +125,8 @@ static int install_volume(vv_context *c, const void *src, bool src_on_device, in
     const size_t bytes = (size_t)nx * ny * nz * vsz;
     if (bytes > 0xFFFFFFFFull + 1ull)
         return fail(c, VV_ERR_INVALID, "load_volume: volumes above 4 GiB need the bricked path (not in this build)");
-    if ((size_t)nx * ny * vsz >= (1u << 24) * 1ull * 256)   // slice_bytes must stay a sane 32-bit stride
-        return fail(c, VV_ERR_INVALID, "load_volume: slice too large");
+    if ((size_t)nx * vsz >= (1u << 24) || nx >= (1 << 24) || ny >= (1 << 24) || nz >= (1 << 24))
+        return fail(c, VV_ERR_INVALID, "load_volume: a volume row must be below 16 MiB and each dimension below 2^24");
     HIPCHK(c, hipSetDevice(c->device));
     // one slice + one row + 16 bytes of zero padding: weight-0 corner fetches of edge
     // samples land here instead of needing index clamps (see vv_device.h VolumeView)
@@ -183,6 +183,7 @@ static VolumeView view_of(const vv_context *c)
     V.data = c->d_vol; V.nx = c->nx; V.ny = c->ny; V.nz = c->nz;
     V.row_bytes = (uint32_t)c->nx * vsz;
     V.slice_bytes = (uint32_t)c->nx * (uint32_t)c->ny * vsz;
+    V.big_slice = V.slice_bytes >= (1u << 24);
     return V;
 }
 

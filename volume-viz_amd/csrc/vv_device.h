@@ -37,6 +37,7 @@ struct VolumeView {
     int nx, ny, nz;
     uint32_t row_bytes;     // nx * sizeof(voxel)
     uint32_t slice_bytes;   // nx*ny * sizeof(voxel)
+    int big_slice;          // slice_bytes >= 2^24: needs a full 32-bit multiply
 };
 
 // Everything a frame needs that is uniform over the launch.
@@ -227,9 +228,9 @@ __device__ __forceinline__ float axis_coord(float x, float n, float nm1, uint32_
     // clamp addressing: for xb < 0 the result is texel 0, for xb >= n-1 texel n-1;
     // clamping the coordinate gives the same value with weight 0.
     xb = __builtin_amdgcn_fmed3f(xb, 0.0f, nm1);
-    float fl = floorf(xb);
-    float a = xb - fl;
-    i = (uint32_t)fl;
+    // xb >= 0: truncation is floor (one v_cvt_u32_f32) and v_fract_f32 is xb - floor(xb) exactly
+    i = (uint32_t)xb;
+    float a = __builtin_amdgcn_fractf(xb);
     if (TEX8) {
         // round to 8 fractional bits, ties to even: adding 1.5*2^15 makes ulp = 2^-8
         const float magic = 49152.0f;
@@ -253,17 +254,25 @@ __device__ __forceinline__ float tex3d_raw(const VolumeView &V, float px, float 
     const char *b01 = b00 + V.slice_bytes;
     const char *b11 = b01 + V.row_bytes;
     float c000, c100, c010, c110, c001, c101, c011, c111;
+    // row/slice offsets: 24-bit multiplies are full rate (v_mul_lo_u32 is quarter rate); indices
+    // are < 2^24 and row_bytes < 2^24 always, slice_bytes < 2^24 unless V.big_slice
+    const uint32_t yz = __umul24(iy, V.row_bytes) + (V.big_slice ? iz * V.slice_bytes : __umul24(iz, V.slice_bytes));
     if (VOXEL == VV_VOXEL_F32) {
-        uint32_t off = ix * 4u + iy * V.row_bytes + iz * V.slice_bytes;
+        uint32_t off = ix * 4u + yz;
         float2u a = *(const float2u *)(b00 + off), b = *(const float2u *)(b10 + off);
         float2u c = *(const float2u *)(b01 + off), d = *(const float2u *)(b11 + off);
         c000 = a.x; c100 = a.y; c010 = b.x; c110 = b.y; c001 = c.x; c101 = c.y; c011 = d.x; c111 = d.y;
     } else {
-        uint32_t off = ix + iy * V.row_bytes + iz * V.slice_bytes;
-        uint32_t a = *(const ushort_u *)(b00 + off), b = *(const ushort_u *)(b10 + off);
-        uint32_t c = *(const ushort_u *)(b01 + off), d = *(const ushort_u *)(b11 + off);
-        c000 = (float)(a & 0xffu); c100 = (float)(a >> 8); c010 = (float)(b & 0xffu); c110 = (float)(b >> 8);
-        c001 = (float)(c & 0xffu); c101 = (float)(c >> 8); c011 = (float)(d & 0xffu); c111 = (float)(d >> 8);
+        // u8: two aligned dwords per row (8 voxels from x & ~3) cost less in the address/L1
+        // pipeline than one unaligned 2-byte gather: neighbouring lanes share the dwords.
+        // v_alignbyte shifts the pair so that byte 0 is voxel x.
+        const uint32_t off = (ix & ~3u) + yz, sh = ix & 3u;
+        uint32_t a = __builtin_amdgcn_alignbyte(*(const uint32_t *)(b00 + off + 4), *(const uint32_t *)(b00 + off), sh);
+        uint32_t b = __builtin_amdgcn_alignbyte(*(const uint32_t *)(b10 + off + 4), *(const uint32_t *)(b10 + off), sh);
+        uint32_t c = __builtin_amdgcn_alignbyte(*(const uint32_t *)(b01 + off + 4), *(const uint32_t *)(b01 + off), sh);
+        uint32_t d = __builtin_amdgcn_alignbyte(*(const uint32_t *)(b11 + off + 4), *(const uint32_t *)(b11 + off), sh);
+        c000 = (float)(a & 0xffu); c100 = (float)((a >> 8) & 0xffu); c010 = (float)(b & 0xffu); c110 = (float)((b >> 8) & 0xffu);
+        c001 = (float)(c & 0xffu); c101 = (float)((c >> 8) & 0xffu); c011 = (float)(d & 0xffu); c111 = (float)((d >> 8) & 0xffu);
     }
     float c00 = __builtin_fmaf(wx, c100 - c000, c000);
     float c10 = __builtin_fmaf(wx, c110 - c010, c010);
