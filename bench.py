@@ -46,6 +46,9 @@ def workload(args, world):
         n = 1024
         fw = args.frame_of or world
         W, H, steps = FRAMES.get(fw, (int(1920 * fw ** 0.5), int(1080 * fw ** 0.5), 512))
+    elif args.config == "c5":     # 2048^3 f32 (32 GiB, > 4 GiB addressing path), Phong: BASELINE configs[4] on one GPU
+        n, (W, H, steps) = 2048, (1920, 1080, 2048)
+        args.phong = True
     elif args.config == "c2":
         n, (W, H, steps) = 256, (1280, 720, 256)
     else:   # c1 geometry on the GPU (the CPU-runnable case)
@@ -60,7 +63,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3"])
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--volume", default="noise", choices=["noise", "brain"])
     ap.add_argument("--tf", default="ramp", choices=["ramp", "head", "engine"])
     ap.add_argument("--view", default="a", choices=["a", "b"])

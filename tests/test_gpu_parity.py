@@ -315,9 +315,9 @@ def test_render_interleaved_shards(ctx, W, H):
 
 @pytest.mark.parametrize("view", ["a", "b", "c"])
 def test_staged_kernel_is_bit_identical(ctx, view, monkeypatch):
-    """The opt-in LDS-staged slab march (VV_STAGED=1) must produce the same frames and sample
-    counts as the oracle: u8 and f32, every slice mode, ragged volume sizes, ERT modes."""
-    monkeypatch.setenv("VV_STAGED", "1")
+    """The opt-in wave-private LDS brick cache march (VV_WSTAGED=1) must produce the same frames
+    and sample counts as the oracle: u8 and f32, every slice mode, ragged volume sizes, ERT modes."""
+    monkeypatch.setenv("VV_WSTAGED", "1")
     tf = vv.transfer_preset(vv.TF_ENGINE)
     cam = _cam(view)
     for dims, dtype, st in (((64, 64, 64), np.uint8, vv.SLICE_NONE), ((48, 40, 36), np.float32, vv.SLICE_PLANE),

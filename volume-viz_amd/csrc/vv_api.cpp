@@ -465,12 +465,14 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
-        // The LDS-staged slab march (vv_raymarch_staged.hip) is bit-identical but, as measured on
-        // MI355X in round 1, slower than the gather kernel (C3: 4.0 ms vs 1.5 ms): opt-in only.
-        // It needs 16-byte aligned volume rows.
-        bool staged = false;
-        if (const char *e = getenv("VV_STAGED")) staged = atoi(e) != 0 && (A.V.row_bytes % 16u) == 0 && !A.V.big;
-        if (staged) launch_raymarch_staged(A, st); else launch_raymarch(A, st);
+        // Wave-private LDS brick cache (vv_raymarch_wstaged.hip): bit-identical to march_kernel
+        // but, as measured on MI355X in round 1, slower (C3 along z: 2.6 ms vs 1.6 ms; rotated
+        // view: 8.8 ms vs 6.8 ms), so it is opt-in (VV_WSTAGED=1) and kept as the base for the
+        // staged design of DESIGN.md section 4.  It needs 16-byte aligned rows and <= 4 GiB.
+        bool wst = false;
+        if (const char *e = getenv("VV_WSTAGED")) wst = atoi(e) != 0 && (A.V.row_bytes % 16u) == 0 && !A.V.big;
+        if (wst) launch_raymarch_wstaged(A, st);
+        else launch_raymarch(A, st);
     }
     HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, hipGetLastError());

@@ -26,7 +26,7 @@ struct MarchArgs {
 
 void launch_rad(const MarchArgs &a, hipStream_t s);
 void launch_raymarch(const MarchArgs &a, hipStream_t s);
-void launch_raymarch_staged(const MarchArgs &a, hipStream_t s);   // LDS-staged slab march (no Phong)
+void launch_raymarch_wstaged(const MarchArgs &a, hipStream_t s);  // wave-private LDS brick cache (no Phong)
 
 struct SliceArgs {
     VolumeView V; int V_type; bool tex8;
