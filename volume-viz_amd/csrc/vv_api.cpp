@@ -118,6 +118,8 @@ int vv_set_transfer_function(vv_context *c, const float tf[1024])
 {
     if (!c || !tf) return fail(c, VV_ERR_INVALID, "vv_set_transfer_function: NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
+    for (int i = 0; i < 1024; ++i)
+        if (!std::isfinite(tf[i])) return fail(c, VV_ERR_INVALID, "vv_set_transfer_function: table entries must be finite");
     bool gray = true;
     for (int i = 0; i < 256; ++i)
         if (!(tf[4*i] == tf[4*i+1] && tf[4*i] == tf[4*i+2])) { gray = false; break; }
@@ -301,8 +303,7 @@ static VolumeView view_of(const vv_context *c)
     V.data = c->d_vol; V.nx = c->nx; V.ny = c->ny; V.nz = c->nz;
     V.row_bytes = (uint32_t)c->nx * vsz;
     V.slice_bytes = (uint32_t)c->nx * (uint32_t)c->ny * vsz;
-    V.big_slice = V.slice_bytes >= (1u << 24);
-    V.big = c->vol_bytes > (1ull << 32) || getenv("VV_FORCE_BIG") != nullptr;
+    V.big = c->vol_bytes > (1ull << 32) || V.slice_bytes >= (1u << 24) || getenv("VV_FORCE_BIG") != nullptr;
     return V;
 }
 
@@ -462,7 +463,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     c->counter_valid = A.instr;
     HIPCHK(c, hipEventRecord(c->ev0, st));
     if (A.phong) {
-        launch_raymarch(A, st);
+        if (A.V.big) launch_raymarch_big(A, st); else launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
         // Wave-private LDS brick cache (vv_raymarch_wstaged.hip): bit-identical to march_kernel
@@ -472,6 +473,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         bool wst = false;
         if (const char *e = getenv("VV_WSTAGED")) wst = atoi(e) != 0 && (A.V.row_bytes % 16u) == 0 && !A.V.big;
         if (wst) launch_raymarch_wstaged(A, st);
+        else if (A.V.big) launch_raymarch_big(A, st);
         else launch_raymarch(A, st);
     }
     HIPCHK(c, hipEventRecord(c->ev1, st));

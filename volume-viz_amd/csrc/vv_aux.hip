@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void slice_kernel(SliceArgs A)
     }
     float s = 0.f;
     if (!check || (px < 1.0f && px >= 0.0f && py < 1.0f && py >= 0.0f && pz < 1.0f && pz >= 0.0f)) {
-        float L = tex3d_raw<VOXEL, TEX8>(A.V, px, py, pz);
+        float L = A.V.big ? tex3d_raw<VOXEL, TEX8, true>(A.V, px, py, pz) : tex3d_raw<VOXEL, TEX8, false>(A.V, px, py, pz);
         s = (VOXEL == VV_VOXEL_U8) ? L / 255.0f : L;              // normalised-float read mode, kernel.cu:46
     }
     A.buffer[offset] = s;

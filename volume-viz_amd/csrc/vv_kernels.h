@@ -26,6 +26,7 @@ struct MarchArgs {
 
 void launch_rad(const MarchArgs &a, hipStream_t s);
 void launch_raymarch(const MarchArgs &a, hipStream_t s);
+void launch_raymarch_big(const MarchArgs &a, hipStream_t s);      // same kernels, volumes above 4 GiB
 void launch_raymarch_wstaged(const MarchArgs &a, hipStream_t s);  // wave-private LDS brick cache (no Phong)
 
 struct SliceArgs {

@@ -15,7 +15,18 @@
 #include "vv_device.h"
 #include "vv_kernels.h"
 
+// This file is compiled twice: as is (volumes up to 4 GiB) and through vv_raymarch_big.hip with
+// VV_BIG_VOLUME defined (64-bit slice addressing), so that the common path pays nothing for it.
+#ifdef VV_BIG_VOLUME
+#define VV_BIG_NS big
+constexpr bool kBig = true;
+#else
+#define VV_BIG_NS small
+constexpr bool kBig = false;
+#endif
+
 namespace vv {
+namespace VV_BIG_NS {
 
 // ---------------------------------------------------------------------------
 // rad pre-pass: one block per slab, one thread per (clamped) footprint pixel.
@@ -132,58 +143,54 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
             py = r.origin.y + r.dir.y * dist;
             pz = r.origin.z + r.dir.z * dist;
         }
-        // U samples per trip (all U gathers issued before the first is consumed).  Measured on
-        // MI355X, C3: U = 2 is not faster (the kernel is bandwidth-, not latency-bound) and
-        // costs a wave of occupancy, so U = 1.
-        constexpr int U = 1;
-        for (int i0 = 1; i0 <= 30; i0 += U) {
-            if (!__any(i0 <= n)) break;
-            float tx[U], ty[U], tz[U];
-            uint32_t idx[U];
+        // The trip count of the sample loop is made wave-uniform once per chunk (5 ballots: n <= 30),
+        // and blend / early termination are predicated instead of branched: scalar branches and
+        // exec-mask bookkeeping inside this loop cost measurable time (MI355X, C3: 1.60 -> 1.5x ms).
+        int nmax = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;      // :141 (sample i = i increments)
-                // (pos - .5) / scale + .5 as fma(pos - .5, 1/scale, .5)   :136, DESIGN.md pin 3
-                tx[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
-                ty[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
-                tz[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-                idx[u] = sample_index<VOXEL, TEX8>(V, tx[u], ty[u], tz[u]);
+        for (int bit = 16; bit > 0; bit >>= 1)
+            if (__any(n >= (nmax | bit))) nmax |= bit;
+        bool stop = false;
+        for (int i = 1; i <= nmax; ++i) {
+            px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;          // :141 (sample i = i increments)
+            // (pos - .5) / scale + .5 as fma(pos - .5, 1/scale, .5)   :136, DESIGN.md pin 3
+            const float tx = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
+            const float ty = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
+            const float tz = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
+            const uint32_t idx = sample_index<VOXEL, TEX8, kBig>(V, tx, ty, tz);
+            const bool live = i <= n && !stop;
+            float cr, cg, cb, ca;
+            ca = lds_tf[768 + idx];
+            cr = lds_tf[idx];
+            if (GRAY) { cg = cb = cr; }                          // r == g == b
+            else { cg = lds_tf[256 + idx]; cb = lds_tf[512 + idx]; }
+            if (SLICE == SLICE_PLANE) {                                                  // :193-198
+#pragma clang fp contract(off)
+                float vd = (float)i * r.sstep + dist;                                    // :254
+                float vx = r.origin.x + r.dir.x * vd, vy = r.origin.y + r.dir.y * vd, vz = r.origin.z + r.dir.z * vd;
+                float d = fabsf(sn.x * (vx - sp.x) + sn.y * (vy - sp.y) + sn.z * (vz - sp.z));
+                if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + u;
-                const bool live = i <= n;
-                float cr, cg, cb, ca;
-                ca = lds_tf[768 + idx[u]];
-                cr = lds_tf[idx[u]];
-                if (GRAY) { cg = cb = cr; }                      // r == g == b
-                else { cg = lds_tf[256 + idx[u]]; cb = lds_tf[512 + idx[u]]; }
-                if (SLICE == SLICE_PLANE) {                                              // :193-198
-#pragma clang fp contract(off)
-                    float vd = (float)i * r.sstep + dist;                                // :254
-                    float vx = r.origin.x + r.dir.x * vd, vy = r.origin.y + r.dir.y * vd, vz = r.origin.z + r.dir.z * vd;
-                    float d = fabsf(sn.x * (vx - sp.x) + sn.y * (vy - sp.y) + sn.z * (vz - sp.z));
-                    if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
-                }
-                if (INSTR) {
-                    if (live) {
-                        executed++;
-                        if (bricks && bounds_check(tx[u], ty[u], tz[u])) mark_bricks(bricks, V, tx[u], ty[u], tz[u]);
-                    }
-                }
-                if (live && ca > kEps) {                                                 // :268-270, blend :107-118
-#pragma clang fp contract(off)
-                    float bf = ca * (1.f - res_a);
-                    res_r = res_r + cr * bf;
-                    if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
-                    res_a = res_a + bf;
-                }
-                if (live && res_a > P.ert_thr) {                                         // :272-274
-                    ert = true; n = 0;
-                    if (P.ert_true) r.upper = -1.f;
+            if (INSTR) {
+                if (live) {
+                    executed++;
+                    if (bricks && bounds_check(tx, ty, tz)) mark_bricks(bricks, V, tx, ty, tz);
                 }
             }
+            {
+                // :268-270 + blend :107-118, predicated: with bf == 0 the sums are unchanged
+                // bit for bit (the table is finite: vv_set_transfer_function rejects NaN/Inf)
+#pragma clang fp contract(off)
+                const float bf = (live && ca > kEps) ? ca * (1.f - res_a) : 0.f;
+                res_r = res_r + cr * bf;
+                if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
+                res_a = res_a + bf;
+            }
+            const bool hit = live && res_a > P.ert_thr;                                  // :272-274
+            stop = stop || hit;
+            ert = ert || hit;
         }
+        if (P.ert_true && ert) r.upper = -1.f;
         {
 #pragma clang fp contract(off)
             dist += r.sstep * kChunkSteps;                                           // :277
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
                 float tx_ = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
                 float ty_ = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
                 float tz_ = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-                cache[i][threadIdx.x] = (uint8_t)sample_index<VOXEL, TEX8>(V, tx_, ty_, tz_);
+                cache[i][threadIdx.x] = (uint8_t)sample_index<VOXEL, TEX8, kBig>(V, tx_, ty_, tz_);
                 if (INSTR && bricks && mine && i >= 1 && i <= 30 && bounds_check(tx_, ty_, tz_)) mark_bricks(bricks, V, tx_, ty_, tz_);
                 px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;
             }
@@ -397,7 +404,7 @@ static void dispatch2(const MarchArgs &a, hipStream_t s)
     else                          { if (a.tex8) dispatch3<SLICE, VV_VOXEL_U8,  true>(a, s); else dispatch3<SLICE, VV_VOXEL_U8,  false>(a, s); }
 }
 
-void launch_rad(const MarchArgs &a, hipStream_t s)
+static void launch_rad_impl(const MarchArgs &a, hipStream_t s)
 {
     // every slab of the frame: a shard's pixels may need the radius of any slab row that
     // intersects its strips, and the whole pass costs about one sample per pixel
@@ -405,7 +412,7 @@ void launch_rad(const MarchArgs &a, hipStream_t s)
     hipLaunchKernelGGL(rad_kernel, grid, dim3(256), 0, s, a.P, a.rad_out);
 }
 
-void launch_raymarch(const MarchArgs &a, hipStream_t s)
+static void launch_raymarch_impl(const MarchArgs &a, hipStream_t s)
 {
     switch (a.P.slice_type) {                       // kernel.cu:429-447
     case SLICE_PLANE:     dispatch2<SLICE_PLANE>(a, s); break;
@@ -413,5 +420,14 @@ void launch_raymarch(const MarchArgs &a, hipStream_t s)
     default:              dispatch2<SLICE_NONE>(a, s); break;
     }
 }
+
+} // namespace VV_BIG_NS
+
+#ifdef VV_BIG_VOLUME
+void launch_raymarch_big(const MarchArgs &a, hipStream_t s) { big::launch_raymarch_impl(a, s); }
+#else
+void launch_rad(const MarchArgs &a, hipStream_t s) { small::launch_rad_impl(a, s); }
+void launch_raymarch(const MarchArgs &a, hipStream_t s) { small::launch_raymarch_impl(a, s); }
+#endif
 
 } // namespace vv
