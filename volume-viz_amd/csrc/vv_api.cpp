@@ -440,6 +440,16 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         if (ax >= 0.97f * sqrtf(ax * ax + ay * ay + az * az)) A.strips.tile_log2w = 5;
     }
     if (const char *e = getenv("VV_TILE_LOG2W")) { int t = atoi(e); if (t >= 3 && t <= 5) A.strips.tile_log2w = t; }
+    // Occupancy cap + gathers in flight (speed only; measured on MI355X):
+    //   volume beyond the caches (> 1 GiB), aligned view : 2 blocks per CU, 2 samples per trip
+    //   volume beyond the caches, rotated view           : 1 block  per CU, 3 samples per trip
+    //   smaller volumes                                  : 3 blocks per CU, 2 samples per trip
+    // LDS per block = 4 KB table + reserve; 160 KB per CU.  VV_LDS_RESERVE / VV_UNROLL override.
+    const bool beyond_caches = c->vol_bytes > (1ull << 30);
+    A.unroll = (beyond_caches && A.strips.tile_log2w == 3) ? 3 : 2;
+    A.lds_reserve = !beyond_caches ? 49000 : (A.strips.tile_log2w == 5 ? 76000 : 155000);
+    if (const char *e = getenv("VV_UNROLL")) { int t = atoi(e); if (t == 2 || t == 3) A.unroll = t; }
+    if (const char *e = getenv("VV_LDS_RESERVE")) { int t = atoi(e); if (t >= 0 && t <= 155 * 1024) A.lds_reserve = t; }
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
     int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));

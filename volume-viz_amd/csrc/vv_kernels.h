@@ -14,6 +14,8 @@ struct MarchArgs {
     VolumeView  V;
     int V_type;                 // vv_voxel_type
     bool tex8, gray, phong, instr;
+    int lds_reserve;            // march_kernel: dynamic LDS bytes reserved only to cap blocks per CU
+    int unroll;                 // march_kernel: samples per loop trip (2 or 3)
     StripMap strips;                   // march_kernel: strips of 8 pixel rows (n_strips of them)
     SlabMap slabs;                     // march_phong_kernel grid.y = n_regular + 1
     const float4 *tf;           // device, 256 entries

@@ -75,8 +75,13 @@ __device__ __forceinline__ void stage_tf_planar(float *lds_tf, const float4 *__r
 // wave a 2^tw x 2^(6-tw) tile of it (32x2 when screen x runs along the volume's x axis, so
 // that the lanes of a gather walk one memory row; 8x8 otherwise).  blockIdx.x enumerates
 // (strip, tile) pairs of the shard (StripMap).
+//
+// Tuning (MI355X, measured): the kernel lives off the 32 KB L1 of its CU
+// (lanes of one gather share sectors, consecutive rows of a wave share lines), so FEWER resident
+// waves are faster: the launcher reserves unused dynamic LDS to cap a CU at 1-3 blocks
+// (MarchArgs::lds_reserve) and each lane keeps U samples = 4U gathers in flight instead.
 // ---------------------------------------------------------------------------
-template <int SLICE, int VOXEL, bool TEX8, bool GRAY, bool INSTR>
+template <int SLICE, int VOXEL, bool TEX8, bool GRAY, bool INSTR, int U>
 __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                                                     const float4 *__restrict__ tf,
                                                     const float *__restrict__ rad,
@@ -151,44 +156,56 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         for (int bit = 16; bit > 0; bit >>= 1)
             if (__any(n >= (nmax | bit))) nmax |= bit;
         bool stop = false;
-        for (int i = 1; i <= nmax; ++i) {
-            px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;          // :141 (sample i = i increments)
-            // (pos - .5) / scale + .5 as fma(pos - .5, 1/scale, .5)   :136, DESIGN.md pin 3
-            const float tx = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
-            const float ty = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
-            const float tz = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-            const uint32_t idx = sample_index<VOXEL, TEX8, kBig>(V, tx, ty, tz);
-            const bool live = i <= n && !stop;
-            float cr, cg, cb, ca;
-            ca = lds_tf[768 + idx];
-            cr = lds_tf[idx];
-            if (GRAY) { cg = cb = cr; }                          // r == g == b
-            else { cg = lds_tf[256 + idx]; cb = lds_tf[512 + idx]; }
-            if (SLICE == SLICE_PLANE) {                                                  // :193-198
-#pragma clang fp contract(off)
-                float vd = (float)i * r.sstep + dist;                                    // :254
-                float vx = r.origin.x + r.dir.x * vd, vy = r.origin.y + r.dir.y * vd, vz = r.origin.z + r.dir.z * vd;
-                float d = fabsf(sn.x * (vx - sp.x) + sn.y * (vy - sp.y) + sn.z * (vz - sp.z));
-                if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
+        // U samples per trip: their gathers are all issued before the first is consumed.  With
+        // the block count per CU capped (lds_reserve) registers are plentiful and the extra
+        // loads in flight pay.
+        for (int i0 = 1; i0 <= nmax; i0 += U) {
+            float tx[U], ty[U], tz[U];
+            uint32_t idx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;      // :141 (sample i = i increments)
+                // (pos - .5) / scale + .5 as fma(pos - .5, 1/scale, .5)   :136, DESIGN.md pin 3
+                tx[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
+                ty[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
+                tz[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
+                idx[u] = sample_index<VOXEL, TEX8, kBig>(V, tx[u], ty[u], tz[u]);
             }
-            if (INSTR) {
-                if (live) {
-                    executed++;
-                    if (bricks && bounds_check(tx, ty, tz)) mark_bricks(bricks, V, tx, ty, tz);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u;
+                const bool live = i <= n && !stop;
+                float cr, cg, cb, ca;
+                ca = lds_tf[768 + idx[u]];
+                cr = lds_tf[idx[u]];
+                if (GRAY) { cg = cb = cr; }                      // r == g == b
+                else { cg = lds_tf[256 + idx[u]]; cb = lds_tf[512 + idx[u]]; }
+                if (SLICE == SLICE_PLANE) {                                              // :193-198
+#pragma clang fp contract(off)
+                    float vd = (float)i * r.sstep + dist;                                // :254
+                    float vx = r.origin.x + r.dir.x * vd, vy = r.origin.y + r.dir.y * vd, vz = r.origin.z + r.dir.z * vd;
+                    float d = fabsf(sn.x * (vx - sp.x) + sn.y * (vy - sp.y) + sn.z * (vz - sp.z));
+                    if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
                 }
-            }
-            {
-                // :268-270 + blend :107-118, predicated: with bf == 0 the sums are unchanged
-                // bit for bit (the table is finite: vv_set_transfer_function rejects NaN/Inf)
+                if (INSTR) {
+                    if (live) {
+                        executed++;
+                        if (bricks && bounds_check(tx[u], ty[u], tz[u])) mark_bricks(bricks, V, tx[u], ty[u], tz[u]);
+                    }
+                }
+                {
+                    // :268-270 + blend :107-118, predicated: with bf == 0 the sums are unchanged
+                    // bit for bit (the table is finite: vv_set_transfer_function rejects NaN/Inf)
 #pragma clang fp contract(off)
-                const float bf = (live && ca > kEps) ? ca * (1.f - res_a) : 0.f;
-                res_r = res_r + cr * bf;
-                if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
-                res_a = res_a + bf;
+                    const float bf = (live && ca > kEps) ? ca * (1.f - res_a) : 0.f;
+                    res_r = res_r + cr * bf;
+                    if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
+                    res_a = res_a + bf;
+                }
+                const bool hit = live && res_a > P.ert_thr;                              // :272-274
+                stop = stop || hit;
+                ert = ert || hit;
             }
-            const bool hit = live && res_a > P.ert_thr;                                  // :272-274
-            stop = stop || hit;
-            ert = ert || hit;
         }
         if (P.ert_true && ert) r.upper = -1.f;
         {
@@ -375,8 +392,14 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
 {
     const int ntx = (a.P.W + 31) / 32;
     dim3 grid((unsigned)(a.strips.n_strips * ntx));
-    hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR>), grid, dim3(256), 0, s,
-                       a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
+    // a.lds_reserve bytes of (unused) dynamic LDS cap the number of resident blocks per CU:
+    // fewer waves share the 32 KB L1, which this gather kernel needs more than latency hiding
+    if (a.unroll == 3)
+        hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 3>), grid, dim3(256), (size_t)a.lds_reserve, s,
+                           a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
+    else
+        hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 2>), grid, dim3(256), (size_t)a.lds_reserve, s,
+                           a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
 }
 template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 static void launch_phong(const MarchArgs &a, hipStream_t s)

@@ -18,7 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))          # volume-viz_amd/
 REPO_ROOT = os.path.normpath(os.path.join(PKG_ROOT, ".."))
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libvolviz_hip.so")
+LIB_PATH = os.environ.get("VV_LIB", os.path.join(PKG_ROOT, "lib", "libvolviz_hip.so"))
 
 # kernel.cuh:18-20
 SLICE_NONE, SLICE_PLANE, SLICE_PLANE_CUT = -1, 0, 1
