@@ -240,63 +240,91 @@ __device__ __forceinline__ float axis_coord(float x, float n, float nm1, uint32_
     return a;
 }
 
-// The eight corners of a sample: x-pairs of the four (y,z) rows starting at b00 + off.
+// A sample in flight: the raw x-pair loads of its four (y,z) rows plus the interpolation
+// weights.  Fetching (address arithmetic + loads) and finishing (conversion + lerps) are
+// separate so that a kernel can issue the loads of several samples back to back and only
+// then consume them -- the compiler does not reliably do that on its own, and on MI355X it
+// is worth 25 %.
+template <int VOXEL> struct Corners;
+template <> struct Corners<VV_VOXEL_F32> { float2u a, b, c, d; float wx, wy, wz; };
+template <> struct Corners<VV_VOXEL_U8>  { uint32_t a0, a1, b0, b1, c0, c1, d0, d1, sh; float wx, wy, wz; };
+
 template <int VOXEL>
-__device__ __forceinline__ void load_corners(const char *b00, uint32_t row_bytes, uint32_t slice_bytes, uint32_t ix,
-                                             uint32_t yz, float &c000, float &c100, float &c010, float &c110,
-                                             float &c001, float &c101, float &c011, float &c111)
+__device__ __forceinline__ void load_rows(const char *b00, uint32_t row_bytes, uint32_t slice_bytes, uint32_t ix,
+                                          uint32_t yz, Corners<VOXEL> &C)
 {
     const char *b10 = b00 + row_bytes;
     const char *b01 = b00 + slice_bytes;
     const char *b11 = b01 + row_bytes;
-    if (VOXEL == VV_VOXEL_F32) {
-        uint32_t off = ix * 4u + yz;
-        float2u a = *(const float2u *)(b00 + off), b = *(const float2u *)(b10 + off);
-        float2u c = *(const float2u *)(b01 + off), d = *(const float2u *)(b11 + off);
-        c000 = a.x; c100 = a.y; c010 = b.x; c110 = b.y; c001 = c.x; c101 = c.y; c011 = d.x; c111 = d.y;
+    if constexpr (VOXEL == VV_VOXEL_F32) {
+        const uint32_t off = ix * 4u + yz;
+        C.a = *(const float2u *)(b00 + off); C.b = *(const float2u *)(b10 + off);
+        C.c = *(const float2u *)(b01 + off); C.d = *(const float2u *)(b11 + off);
     } else {
         // u8: two aligned dwords per row (8 voxels from x & ~3) cost less in the address/L1
         // pipeline than one unaligned 2-byte gather: neighbouring lanes share the dwords.
-        // v_alignbyte shifts the pair so that byte 0 is voxel x.
-        const uint32_t off = (ix & ~3u) + yz, sh = ix & 3u;
-        uint32_t a = __builtin_amdgcn_alignbyte(*(const uint32_t *)(b00 + off + 4), *(const uint32_t *)(b00 + off), sh);
-        uint32_t b = __builtin_amdgcn_alignbyte(*(const uint32_t *)(b10 + off + 4), *(const uint32_t *)(b10 + off), sh);
-        uint32_t c = __builtin_amdgcn_alignbyte(*(const uint32_t *)(b01 + off + 4), *(const uint32_t *)(b01 + off), sh);
-        uint32_t d = __builtin_amdgcn_alignbyte(*(const uint32_t *)(b11 + off + 4), *(const uint32_t *)(b11 + off), sh);
-        c000 = (float)(a & 0xffu); c100 = (float)((a >> 8) & 0xffu); c010 = (float)(b & 0xffu); c110 = (float)((b >> 8) & 0xffu);
-        c001 = (float)(c & 0xffu); c101 = (float)((c >> 8) & 0xffu); c011 = (float)(d & 0xffu); c111 = (float)((d >> 8) & 0xffu);
+        const uint32_t off = (ix & ~3u) + yz;
+        C.sh = ix & 3u;
+        C.a0 = *(const uint32_t *)(b00 + off); C.a1 = *(const uint32_t *)(b00 + off + 4);
+        C.b0 = *(const uint32_t *)(b10 + off); C.b1 = *(const uint32_t *)(b10 + off + 4);
+        C.c0 = *(const uint32_t *)(b01 + off); C.c1 = *(const uint32_t *)(b01 + off + 4);
+        C.d0 = *(const uint32_t *)(b11 + off); C.d1 = *(const uint32_t *)(b11 + off + 4);
     }
 }
 
-// Trilinear reconstruction in storage units (0..255 for u8, as-is for f32) at
-// normalised texture coordinates p (any value; out-of-range is clamped, NaN -> texel 0).
+// texture coordinates -> weights + loads in flight (no use of the loaded data)
+template <int VOXEL, bool TEX8, bool BIG = false>
+__device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, float py, float pz, Corners<VOXEL> &C)
+{
+    uint32_t ix, iy, iz;
+    C.wx = axis_coord<TEX8>(px, (float)V.nx, (float)(V.nx - 1), ix);
+    C.wy = axis_coord<TEX8>(py, (float)V.ny, (float)(V.ny - 1), iy);
+    C.wz = axis_coord<TEX8>(pz, (float)V.nz, (float)(V.nz - 1), iz);
+    // row/slice offsets: 24-bit multiplies are full rate (v_mul_lo_u32 is quarter rate); indices
+    // and row_bytes are always < 2^24; volumes whose slice_bytes is not take the BIG path.  BIG is a
+    // compile-time choice: a run-time branch here cost 4 % (view along z) to 23 % (rotated view).
+    if (!BIG) {
+        // up to 4 GiB: one 32-bit byte offset per sample added to four scalar bases (saddr + voffset)
+        load_rows<VOXEL>((const char *)V.data, V.row_bytes, V.slice_bytes, ix,
+                         __umul24(iy, V.row_bytes) + __umul24(iz, V.slice_bytes), C);
+    } else {
+        // volumes above 4 GiB (separate kernel instantiations): 64-bit slice base per lane
+        const char *zb = (const char *)V.data + (uint64_t)iz * V.slice_bytes;
+        load_rows<VOXEL>(zb, V.row_bytes, V.slice_bytes, ix, __umul24(iy, V.row_bytes), C);
+    }
+}
+
+// loaded rows -> trilinear value in storage units (0..255 for u8, as-is for f32)
+template <int VOXEL>
+__device__ __forceinline__ float finish_corners(const Corners<VOXEL> &C)
+{
+    float c000, c100, c010, c110, c001, c101, c011, c111;
+    if constexpr (VOXEL == VV_VOXEL_F32) {
+        c000 = C.a.x; c100 = C.a.y; c010 = C.b.x; c110 = C.b.y; c001 = C.c.x; c101 = C.c.y; c011 = C.d.x; c111 = C.d.y;
+    } else {
+        // v_alignbyte shifts each dword pair so that byte 0 is voxel x
+        const uint32_t a = __builtin_amdgcn_alignbyte(C.a1, C.a0, C.sh), b = __builtin_amdgcn_alignbyte(C.b1, C.b0, C.sh);
+        const uint32_t c = __builtin_amdgcn_alignbyte(C.c1, C.c0, C.sh), d = __builtin_amdgcn_alignbyte(C.d1, C.d0, C.sh);
+        c000 = (float)(a & 0xffu); c100 = (float)((a >> 8) & 0xffu); c010 = (float)(b & 0xffu); c110 = (float)((b >> 8) & 0xffu);
+        c001 = (float)(c & 0xffu); c101 = (float)((c >> 8) & 0xffu); c011 = (float)(d & 0xffu); c111 = (float)((d >> 8) & 0xffu);
+    }
+    float c00 = __builtin_fmaf(C.wx, c100 - c000, c000);
+    float c10 = __builtin_fmaf(C.wx, c110 - c010, c010);
+    float c01 = __builtin_fmaf(C.wx, c101 - c001, c001);
+    float c11 = __builtin_fmaf(C.wx, c111 - c011, c011);
+    float c0 = __builtin_fmaf(C.wy, c10 - c00, c00);
+    float c1 = __builtin_fmaf(C.wy, c11 - c01, c01);
+    return __builtin_fmaf(C.wz, c1 - c0, c0);
+}
+
+// Trilinear reconstruction in storage units at normalised texture coordinates p (any value;
+// out-of-range is clamped, NaN -> texel 0).
 template <int VOXEL, bool TEX8, bool BIG = false>
 __device__ __forceinline__ float tex3d_raw(const VolumeView &V, float px, float py, float pz)
 {
-    uint32_t ix, iy, iz;
-    float wx = axis_coord<TEX8>(px, (float)V.nx, (float)(V.nx - 1), ix);
-    float wy = axis_coord<TEX8>(py, (float)V.ny, (float)(V.ny - 1), iy);
-    float wz = axis_coord<TEX8>(pz, (float)V.nz, (float)(V.nz - 1), iz);
-    float c000, c100, c010, c110, c001, c101, c011, c111;
-    // row/slice offsets: 24-bit multiplies are full rate (v_mul_lo_u32 is quarter rate); indices
-    // and row_bytes are always < 2^24; volumes whose slice_bytes is not take the BIG path.  BIG is a compile-time
-    // choice: a run-time branch here cost 4 % (view along z) to 23 % (rotated view) on MI355X.
-    if (!BIG) {
-        // up to 4 GiB: one 32-bit byte offset per sample added to four scalar bases (saddr + voffset)
-        const uint32_t yz = __umul24(iy, V.row_bytes) + __umul24(iz, V.slice_bytes);
-        load_corners<VOXEL>((const char *)V.data, V.row_bytes, V.slice_bytes, ix, yz, c000, c100, c010, c110, c001, c101, c011, c111);
-    } else {
-        // volumes above 4 GiB (separate kernel instantiations): 64-bit slice base per lane, 32-bit in-slice offset
-        const char *zb = (const char *)V.data + (uint64_t)iz * V.slice_bytes;
-        load_corners<VOXEL>(zb, V.row_bytes, V.slice_bytes, ix, __umul24(iy, V.row_bytes), c000, c100, c010, c110, c001, c101, c011, c111);
-    }
-    float c00 = __builtin_fmaf(wx, c100 - c000, c000);
-    float c10 = __builtin_fmaf(wx, c110 - c010, c010);
-    float c01 = __builtin_fmaf(wx, c101 - c001, c001);
-    float c11 = __builtin_fmaf(wx, c111 - c011, c011);
-    float c0 = __builtin_fmaf(wy, c10 - c00, c00);
-    float c1 = __builtin_fmaf(wy, c11 - c01, c01);
-    return __builtin_fmaf(wz, c1 - c0, c0);
+    Corners<VOXEL> C;
+    fetch_corners<VOXEL, TEX8, BIG>(V, px, py, pz, C);
+    return finish_corners<VOXEL>(C);
 }
 
 // kernel.cu:65-71 boundsCheck on all three coordinates: p in [0,1).  A float is in
@@ -311,13 +339,20 @@ __device__ __forceinline__ bool bounds_check(float x, float y, float z)
 // kernel.cu:99-105 sample(): (uchar)(0xff * tex3D) or 0 outside.  For u8 volumes the
 // normalisation and the multiplication cancel, the index is trunc(L) (DESIGN.md pin 2);
 // f32 volumes: trunc(255 * L), saturated.
-template <int VOXEL, bool TEX8, bool BIG = false>
-__device__ __forceinline__ uint32_t sample_index(const VolumeView &V, float px, float py, float pz)
+template <int VOXEL>
+__device__ __forceinline__ uint32_t classify_index(const Corners<VOXEL> &C, float px, float py, float pz)
 {
-    float L = tex3d_raw<VOXEL, TEX8, BIG>(V, px, py, pz);
+    float L = finish_corners<VOXEL>(C);
     float s = (VOXEL == VV_VOXEL_F32) ? L * 255.0f : L;
     uint32_t idx = min((uint32_t)s, 255u);          // v_cvt_u32_f32 saturates; NaN -> 0
     return bounds_check(px, py, pz) ? idx : 0u;
+}
+template <int VOXEL, bool TEX8, bool BIG = false>
+__device__ __forceinline__ uint32_t sample_index(const VolumeView &V, float px, float py, float pz)
+{
+    Corners<VOXEL> C;
+    fetch_corners<VOXEL, TEX8, BIG>(V, px, py, pz, C);
+    return classify_index<VOXEL>(C, px, py, pz);
 }
 
 __device__ __forceinline__ uint32_t pack_rgba(float r, float g, float b, float a)

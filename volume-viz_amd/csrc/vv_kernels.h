@@ -6,7 +6,7 @@
 namespace vv {
 
 // blockIdx.y -> pixel strip (march_kernel) / slab row (march_phong_kernel) of a shard
-struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips; };
+struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips, xcd_band; };
 struct SlabMap  { int r0, band, band_stride, n_regular; };
 
 struct MarchArgs {

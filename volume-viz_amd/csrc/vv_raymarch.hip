@@ -93,7 +93,15 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ntx = (P.W + 31) >> 5;
-    const int strip = blockIdx.x / ntx, tile_x = blockIdx.x % ntx;
+    int strip, tile_x;
+    if (M.xcd_band > 0) {
+        // XCD-aware order (speed only): linear block L runs on XCD L % 8 (round-robin dispatch);
+        // XCD k walks bands k, k+8, ... of xcd_band strips so that neighbouring tiles share an L2
+        const int L = blockIdx.x, per_band = ntx * M.xcd_band;
+        const int xcd = L & 7, j = L >> 3;
+        const int band = (j / per_band) * 8 + xcd, w = j % per_band;
+        strip = band * M.xcd_band + w / ntx; tile_x = w % ntx;
+    } else { strip = blockIdx.x / ntx; tile_x = blockIdx.x % ntx; }
     // wave tile = 2^tw x 2^(6-tw) pixels; the 4 waves of a block tile a 32x8 strip
     const int tw = M.tile_log2w, th = 6 - tw;
     const int wx = wave & ((32 >> tw) - 1), wy = wave >> (5 - tw);
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         // loads in flight pay.
         for (int i0 = 1; i0 <= nmax; i0 += U) {
             float tx[U], ty[U], tz[U];
-            uint32_t idx[U];
+            Corners<VOXEL> C[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;      // :141 (sample i = i increments)
@@ -169,8 +177,12 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                 tx[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
                 ty[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
                 tz[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-                idx[u] = sample_index<VOXEL, TEX8, kBig>(V, tx[u], ty[u], tz[u]);
+                fetch_corners<VOXEL, TEX8, kBig>(V, tx[u], ty[u], tz[u], C[u]);
             }
+            __builtin_amdgcn_sched_barrier(0);           // all 4U gathers are issued before the first is consumed
+            uint32_t idx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) idx[u] = classify_index<VOXEL>(C[u], tx[u], ty[u], tz[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = i0 + u;
@@ -391,7 +403,12 @@ template <int SLICE, int VOXEL, bool TEX8, bool GRAY, bool INSTR>
 static void launch_march(const MarchArgs &a, hipStream_t s)
 {
     const int ntx = (a.P.W + 31) / 32;
-    dim3 grid((unsigned)(a.strips.n_strips * ntx));
+    unsigned nblocks = (unsigned)(a.strips.n_strips * ntx);
+    if (a.strips.xcd_band > 0) {
+        const int nbands = (a.strips.n_strips + a.strips.xcd_band - 1) / a.strips.xcd_band;
+        nblocks = (unsigned)(((nbands + 7) / 8) * 8 * a.strips.xcd_band * ntx);
+    }
+    dim3 grid(nblocks);
     // a.lds_reserve bytes of (unused) dynamic LDS cap the number of resident blocks per CU:
     // fewer waves share the 32 KB L1, which this gather kernel needs more than latency hiding
     if (a.unroll == 3)
