@@ -454,6 +454,8 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     A.lds_reserve = !beyond_caches ? 49000 : (A.strips.tile_log2w == 5 ? 76000 : 155000);
     if (const char *e = getenv("VV_UNROLL")) { int t = atoi(e); if (t == 2 || t == 3) A.unroll = t; }
     if (const char *e = getenv("VV_LDS_RESERVE")) { int t = atoi(e); if (t >= 0 && t <= 155 * 1024) A.lds_reserve = t; }
+    A.lds_reserve_phong = beyond_caches ? 40000 : 20000;    // 3 / 4 blocks per CU (measured: 3.02 -> 2.68 ms on C3 + Phong)
+    if (const char *e = getenv("VV_LDS_RESERVE_PHONG")) { int t = atoi(e); if (t >= 0 && t <= 146 * 1024) A.lds_reserve_phong = t; }
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
     int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));

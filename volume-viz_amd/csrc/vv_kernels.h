@@ -16,6 +16,7 @@ struct MarchArgs {
     bool tex8, gray, phong, instr;
     int lds_reserve;            // march_kernel: dynamic LDS bytes reserved only to cap blocks per CU
     int unroll;                 // march_kernel: samples per loop trip (2 or 3)
+    int lds_reserve_phong;      // march_phong_kernel: same occupancy cap (its own LDS is 13.3 KB)
     StripMap strips;                   // march_kernel: strips of 8 pixel rows (n_strips of them)
     SlabMap slabs;                     // march_phong_kernel grid.y = n_regular + 1
     const float4 *tf;           // device, 256 entries

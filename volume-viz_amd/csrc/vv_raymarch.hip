@@ -336,13 +336,26 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
 #pragma clang fp contract(off)
                 px = r.origin.x + r.dir.x * dist; py = r.origin.y + r.dir.y * dist; pz = r.origin.z + r.dir.z * dist;
             }
-            for (int i = 0; i < kCacheDepth; ++i) {
-                float tx_ = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
-                float ty_ = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
-                float tz_ = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-                cache[i][threadIdx.x] = (uint8_t)sample_index<VOXEL, TEX8, kBig>(V, tx_, ty_, tz_);
-                if (INSTR && bricks && mine && i >= 1 && i <= 30 && bounds_check(tx_, ty_, tz_)) mark_bricks(bricks, V, tx_, ty_, tz_);
-                px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;
+            // 4 samples (16 gathers) in flight per trip, issued before any is consumed
+            constexpr int PU = 4;
+            for (int i0 = 0; i0 < kCacheDepth; i0 += PU) {
+                float tx_[PU], ty_[PU], tz_[PU];
+                Corners<VOXEL> C[PU];
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    tx_[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
+                    ty_[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
+                    tz_[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
+                    fetch_corners<VOXEL, TEX8, kBig>(V, tx_[u], ty_[u], tz_[u], C[u]);
+                    px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int i = i0 + u;
+                    cache[i][threadIdx.x] = (uint8_t)classify_index<VOXEL>(C[u], tx_[u], ty_[u], tz_[u]);
+                    if (INSTR && bricks && mine && i >= 1 && i <= 30 && bounds_check(tx_[u], ty_[u], tz_[u])) mark_bricks(bricks, V, tx_[u], ty_[u], tz_[u]);
+                }
             }
         }
         __syncthreads();
@@ -422,7 +435,7 @@ template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 static void launch_phong(const MarchArgs &a, hipStream_t s)
 {
     dim3 grid(a.P.nbx, a.slabs.n_regular + 1);
-    hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), 0, s,
+    hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), (size_t)a.lds_reserve_phong, s,
                        a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
 }
 
