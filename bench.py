@@ -249,6 +249,12 @@ def main():
             sN += O.render(host_vol, tf, W, H, cam, options=copts, threads=cores)[1]
             reps += 1
         dt = time.perf_counter() - t
+        # single-thread rate on one centre slab row (BASELINE.md section 3 asks for 1 and nproc)
+        t1 = time.perf_counter()
+        _, s1t = O.render(host_vol, tf, W, H, cam, options=vv.make_options(slab_rows=(mid, mid + 1), **cbase), threads=1)
+        d1t = time.perf_counter() - t1
+        out["cpu_baseline_1thread"] = {"value": round(s1t / d1t / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                       "sample": f"centre slab row ({s1t} samples in {d1t:.1f} s)"}
         what = f"{reps} x the whole frame" if rows == nby else f"slab rows [{lo},{lo + rows}) of {nby} of the same frame"
         out["cpu_baseline"] = {"value": round(sN / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
                                "sample": f"{what} ({sN} samples in {dt:.1f} s; oracle/vvo.c, OpenMP, {cores} threads)"}

@@ -369,17 +369,22 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
                 float4 e = lds_tf[s];
                 float cr = e.x, cg = e.y, cb = e.z, ca = e.w;
                 if (ca > kEps) {                                                      // :164 (phong is on)
-                    float f = cache[i - 1][threadIdx.x] / 255.f, a = cache[i + 1][threadIdx.x] / 255.f;
-                    float l = cache[i][nl] / 255.f, rr = cache[i][nr] / 255.f;
-                    float t = cache[i][nt] / 255.f, b = cache[i][nb] / 255.f;
-                    float gx = (rr - l) / (P.tan_fov_x * vd), gy = (t - b) / (P.tan_fov_y * vd),
-                          gz = (a - f) / (r.sstep * 2.f);                             // :175-178, :259-263
-                    if (gx != 0.f && gy != 0.f && gz != 0.f) {
-                        float inv = 1.0f / sqrtf(gx * gx + gy * gy + gz * gz);
-                        gx *= inv; gy *= inv; gz *= inv;
+                    const uint32_t qf = cache[i - 1][threadIdx.x], qa = cache[i + 1][threadIdx.x];
+                    const uint32_t ql = cache[i][nl], qr = cache[i][nr], qt = cache[i][nt], qb = cache[i][nb];
+                    float direct = 0.f;
+                    // all three central differences zero (inside a plateau): the gradient is (0,0,0),
+                    // it is not normalised (:180) and direct = clamp(0) = 0 -- skip the divisions
+                    if (!(qr == ql && qt == qb && qa == qf)) {
+                        float f = qf / 255.f, a = qa / 255.f, l = ql / 255.f, rr = qr / 255.f, t = qt / 255.f, b = qb / 255.f;
+                        float gx = (rr - l) / (P.tan_fov_x * vd), gy = (t - b) / (P.tan_fov_y * vd),
+                              gz = (a - f) / (r.sstep * 2.f);                         // :175-178, :259-263
+                        if (gx != 0.f && gy != 0.f && gz != 0.f) {
+                            float inv = 1.0f / sqrtf(gx * gx + gy * gy + gz * gz);
+                            gx *= inv; gy *= inv; gz *= inv;
+                        }
+                        direct = (gx * -1.f + gy * -1.f + gz * 1.f) * 0.3f;           // :183
+                        direct = fmaxf(0.f, fminf(direct, 0.3f));
                     }
-                    float direct = (gx * -1.f + gy * -1.f + gz * 1.f) * 0.3f;         // :183
-                    direct = fmaxf(0.f, fminf(direct, 0.3f));
                     cr = cr * 0.7f + direct; cg = cg * 0.7f + direct; cb = cb * 0.7f + direct;
                 }
                 if (SLICE == SLICE_PLANE) {
