@@ -35,6 +35,9 @@ __global__ __launch_bounds__(256) void rad_kernel(FrameParams P, float *__restri
 {
     __shared__ float red[256];
     const int bx = blockIdx.x, by = blockIdx.y;
+    // a shard only needs the radii of the slab rows that own its pixel rows: its own bands
+    // (bands are whole slab rows) and, when H == 1 (mod 14), the last slab row (pin 10)
+    if (!row_owned(P, by * kSlab) && !(P.conflict_y && by == P.nby - 1)) return;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     int x = bx * kSlab + tx - 1, y = by * kSlab + ty - 1;                 // kernel.cu:294-295
     x = max(slab_lo(bx), min(x, slab_up(bx, P.W) - 1));                   // :307-308
@@ -464,8 +467,7 @@ static void dispatch2(const MarchArgs &a, hipStream_t s)
 
 static void launch_rad_impl(const MarchArgs &a, hipStream_t s)
 {
-    // every slab of the frame: a shard's pixels may need the radius of any slab row that
-    // intersects its strips, and the whole pass costs about one sample per pixel
+    // one block per slab of the frame; blocks of slab rows this shard does not own exit at once
     dim3 grid(a.P.nbx, a.P.nby);
     hipLaunchKernelGGL(rad_kernel, grid, dim3(256), 0, s, a.P, a.rad_out);
 }
