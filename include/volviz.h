@@ -194,6 +194,27 @@ int  vv_slice_advanced(vv_context *ctx, float *buffer, size_t height, size_t wid
                        const float scale[3], int filter,
                        int out_on_device, void *stream);
 
+/* The first pass on its own (firstpass.vert:6, firstpass.frag:4, glwidget.cpp:198-228): the
+ * RGBA8 images the reference's two FBOs would hold for this camera -- cube-space entry (front
+ * faces) and exit (back faces) positions, UNORM8-rounded, alpha 255 where a face is visible and
+ * the clear colour (0,0,0,0) elsewhere.  A host without GL can feed them to VV_RAYS_IMAGES.
+ * rays must be VV_RAYS_ANALYTIC.  Images are img_w x img_h x 4 bytes, row 0 = bottom.        */
+int  vv_first_pass(vv_context *ctx, int img_w, int img_h, const struct camera_params *camera,
+                   const vv_ray_source *rays, uint8_t *front_rgba, uint8_t *back_rgba,
+                   int out_on_device, void *stream);
+
+/* Cutting plane of the canonical slice views (GLWidget::setSliceCanonical, glwidget.cpp:743-788)
+ * and the orientation rule applied before the plane goes into slice_params (glwidget.cpp:243-258:
+ * the normal is negated when flip_cross_section && n.y < -1e-6, or !flip && n.y > 1e-6).       */
+int  vv_cut_plane_canonical(int orientation, float displace, float point[3], float normal[3]);
+int  vv_cut_plane_to_slice_params(int slice_type, const float point[3], const float normal[3],
+                                  int flip_cross_section, struct slice_params *out);
+
+/* Slice buffer -> the BGRA image SliceWidget shows (slicewidget.cpp:108-121): grey value
+ * (unsigned)(f*255), alpha 255, written mirrored at bits[size - offset] with offset = j*height+i;
+ * bits[0] and elements whose index falls outside stay untouched.  bgra: width*height*4 bytes. */
+int  vv_slice_to_bgra(const float *slice, size_t height, size_t width, uint8_t *bgra);
+
 /* Slice transform of the free-form slice view: SliceWidget::getTransformationMatrix
  * (slicewidget.cpp:147-165) = T(+.5) T(dx,dy,dz) Rx(theta) Ry(phi) Rz(psi) T(-.5),
  * binary32, row-major, multiplied left to right (cs123math/CS123Matrix.cpp:27-62).

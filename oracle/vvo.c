@@ -312,9 +312,18 @@ static inline f3 cross3(f3 a, f3 b)
  * and the look-at basis of camera.cpp:78-91, intersected with the box
  * [-scale, scale]; cubeSpace = world/2 + 0.5 (firstpass.vert:6 with the glScalef
  * of glwidget.cpp:198).  A face that is not visible leaves the clear colour 0. */
+static void analytic_endpoints_vis(const vv_ray_source *rs, const struct camera_params *cam,
+                                   int W, int H, int x, int y, f3 *front, f3 *back, int *vis_f, int *vis_b);
 static void analytic_endpoints(const vv_ray_source *rs, const struct camera_params *cam,
                                int W, int H, int x, int y, f3 *front, f3 *back)
 {
+    int vf, vb;
+    analytic_endpoints_vis(rs, cam, W, H, x, y, front, back, &vf, &vb);
+}
+static void analytic_endpoints_vis(const vv_ray_source *rs, const struct camera_params *cam,
+                                   int W, int H, int x, int y, f3 *front, f3 *back, int *vis_f, int *vis_b)
+{
+    *vis_f = 0; *vis_b = 0;
     f3 look = norm3(mk3(rs->look[0], rs->look[1], rs->look[2]));
     f3 up0  = mk3(rs->up[0], rs->up[1], rs->up[2]);
     f3 side = norm3(cross3(look, up0));
@@ -339,9 +348,11 @@ static void analytic_endpoints(const vv_ray_source *rs, const struct camera_para
     }
     *front = mk3(0.f, 0.f, 0.f); *back = mk3(0.f, 0.f, 0.f);
     if (miss || !(tmin <= tmax) || !(tmax > 0.0f)) return;
+    *vis_b = 1;
     f3 pb = add3(o, scl3(d, tmax));
     *back = mk3(pb.x * 0.5f + 0.5f, pb.y * 0.5f + 0.5f, pb.z * 0.5f + 0.5f);
     if (tmin > 0.0f) {
+        *vis_f = 1;
         f3 pf = add3(o, scl3(d, tmin));
         *front = mk3(pf.x * 0.5f + 0.5f, pf.y * 0.5f + 0.5f, pf.z * 0.5f + 0.5f);
     }
@@ -352,6 +363,24 @@ static void analytic_endpoints(const vv_ray_source *rs, const struct camera_para
             float q = floorf(c * 255.0f + 0.5f);
             *p[i] = q / 255.f;
         }
+    }
+}
+
+/* The two FBO images of the first pass (glwidget.cpp:200-228) for an analytic camera: UNORM8
+ * cube-space positions, alpha 255 where the face is visible, clear colour 0 elsewhere. */
+void vvo_first_pass(const vv_ray_source *rs, const struct camera_params *cam, int W, int H,
+                    uint8_t *front_rgba, uint8_t *back_rgba)
+{
+    vv_ray_source q = *rs;
+    q.quantize8 = 1;                                  /* end points come back as k/255 */
+    for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) {
+        f3 f, b;
+        int vis_f, vis_b;
+        analytic_endpoints_vis(&q, cam, W, H, x, y, &f, &b, &vis_f, &vis_b);
+        uint8_t *pf = front_rgba + 4 * ((size_t)y * W + x), *pb = back_rgba + 4 * ((size_t)y * W + x);
+        pf[0] = (uint8_t)(f.x * 255.f + 0.5f); pf[1] = (uint8_t)(f.y * 255.f + 0.5f); pf[2] = (uint8_t)(f.z * 255.f + 0.5f);
+        pb[0] = (uint8_t)(b.x * 255.f + 0.5f); pb[1] = (uint8_t)(b.y * 255.f + 0.5f); pb[2] = (uint8_t)(b.z * 255.f + 0.5f);
+        pf[3] = vis_f ? 255 : 0; pb[3] = vis_b ? 255 : 0;
     }
 }
 

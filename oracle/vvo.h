@@ -67,6 +67,9 @@ void vvo_slice_matrix(float dx, float dy, float dz, float theta, float phi, floa
 void vvo_ray_endpoints(const vv_ray_source *rs, const struct camera_params *cam,
                        int W, int H, int x, int y, float front[3], float back[3]);
 
+void vvo_first_pass(const vv_ray_source *rs, const struct camera_params *cam, int W, int H,
+                    uint8_t *front_rgba, uint8_t *back_rgba);
+
 /* ---- ray march: kernel.cu:281-367 over the launch geometry of kernel.cu:415-447.
  * Returns the number of executed samples (voxelDist <= upper iterations of the
  * inner loop, kernel.cu:253-257) over written pixels.  threads <= 0: all cores. */

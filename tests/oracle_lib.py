@@ -45,6 +45,7 @@ def oracle() -> C.CDLL:
                                    C.POINTER(vv.vv_ray_source), C.POINTER(vv.vv_render_options), vp, i]
         lib.vvo_render.restype = C.c_ulonglong
         lib.vvo_generate_noise_u8.argtypes = [vp, i, i, i, C.c_uint32]
+        lib.vvo_first_pass.argtypes = [C.POINTER(vv.vv_ray_source), C.POINTER(vv.camera_params), i, i, vp, vp]
         _oracle = lib
     return _oracle
 
@@ -133,6 +134,13 @@ def ray_endpoints(rs, cam: vv.Camera, W, H, x, y):
     cp = cam.params(W, H)
     oracle().vvo_ray_endpoints(C.byref(rs), C.byref(cp), W, H, x, y, f.ctypes.data, b.ctypes.data)
     return f, b
+
+
+def first_pass(cam: vv.Camera, W, H):
+    front = np.zeros((H, W, 4), np.uint8); back = np.zeros((H, W, 4), np.uint8)
+    rs = vv.analytic_rays(cam); cp = cam.params(W, H)
+    oracle().vvo_first_pass(C.byref(rs), C.byref(cp), W, H, front.ctypes.data, back.ctypes.data)
+    return front, back
 
 
 def render(vol, tf, width, height, cam: vv.Camera, *, slice=None, phong=False, rays=None, options=None,

@@ -237,6 +237,27 @@ def test_render_image_ray_source(ctx):
         assert (got[..., 3] > 0).mean() > 0.1
 
 
+def test_first_pass_images(ctx):
+    """vv_first_pass: the FBO pair of the GL first pass, and a render fed with them."""
+    for tag, scale in (("a", (1, 1, 1)), ("b", (1.0, 1.0, 0.8)), ("c", (1.57, 1.0, 1.0))):
+        cam = _cam(tag, scale)
+        gf, gb = ctx.first_pass(255, 180, cam)
+        of, ob = O.first_pass(cam, 255, 180)
+        assert np.array_equal(gf, of) and np.array_equal(gb, ob), tag
+        assert 0.05 < (gb[..., 3] == 255).mean() < 0.95 and np.array_equal(gf[..., 3] == 255, gb[..., 3] == 255)
+    vol = O.draw_default_brain(32, 32, 32)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    got = ctx.render(85, 60, cam, rays=vv.image_rays(gf, gb), phong=True)
+    want, _ = O.render(vol, tf, 85, 60, cam, rays=vv.image_rays(of, ob), phong=True)
+    assert_frames_close(got, want)
+    # camera inside the cube: the front faces are culled, only the back image is filled
+    inside = vv.Camera(origin=(0.1, 0.0, -0.2), look_at=(0.0, 0.0, 1.0))
+    gf, gb = ctx.first_pass(64, 48, inside)
+    of, ob = O.first_pass(inside, 64, 48)
+    assert np.array_equal(gf, of) and np.array_equal(gb, ob) and not gf.any() and (gb[..., 3] == 255).all()
+
+
 def test_render_quantised_analytic(ctx):
     vol = O.draw_default_brain(32, 32, 32)
     tf = vv.transfer_preset(vv.TF_HEAD)

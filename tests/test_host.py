@@ -81,6 +81,42 @@ def test_t3d_reads_reference_written_file(golden_dir, tmp_path):
         assert list(dims) == [16, 16, 16] and np.array_equal(out, buf)
 
 
+def test_cut_plane_helpers():
+    # GLWidget::setSliceCanonical (glwidget.cpp:757-776)
+    for o, axis in ((vv.HORIZONTAL, 1), (vv.SAGITTAL, 2), (vv.CORONAL, 0)):
+        pt, n = vv.cut_plane_canonical(o, 0.3)
+        want = np.zeros(3, np.float32); want[axis] = 1
+        assert np.array_equal(n, want) and np.array_equal(pt, want * np.float32(0.3))
+    with pytest.raises(vv.VolvizError):
+        vv.cut_plane_canonical(vv.FREE_FORM, 0.1)
+    # orientation rule of glwidget.cpp:243-252
+    sp = vv.cut_plane_to_slice_params(vv.SLICE_PLANE_CUT, (0.1, 0.2, 0.3), (0.0, 0.5, 0.5), flip=False)
+    assert sp.type == 1 and list(sp.params) == [np.float32(v) for v in (0.1, 0.2, 0.3, -0.0, -0.5, -0.5)]
+    sp = vv.cut_plane_to_slice_params(vv.SLICE_PLANE, (0.1, 0.2, 0.3), (0.0, 0.5, 0.5), flip=True)
+    assert list(sp.params)[3:] == [0.0, 0.5, 0.5]
+    sp = vv.cut_plane_to_slice_params(vv.SLICE_PLANE, (0, 0, 0), (1.0, -0.5, 0.0), flip=True)
+    assert list(sp.params)[3:] == [-1.0, 0.5, -0.0]
+    sp = vv.cut_plane_to_slice_params(vv.SLICE_PLANE, (0, 0, 0), (1.0, 1e-7, 0.0), flip=False)   # |n.y| below 1e-6: kept
+    assert list(sp.params)[3:] == [1.0, np.float32(1e-7), 0.0]
+    assert vv.cut_plane_to_slice_params(vv.SLICE_NONE, (1, 2, 3), (4, 5, 6)).type == -1
+
+
+def test_slice_to_bgra():
+    # slicewidget.cpp:108-121: grey = (unsigned)(f*255), mirrored at bits[size - offset]
+    h, w = 4, 4
+    buf = np.linspace(0, 1, h * w, dtype=np.float32)
+    out = vv.slice_to_bgra(buf, h, w, fill=7)
+    assert np.all(out[0] == 7)                               # bits[0] is never written
+    for off in range(1, h * w):
+        v = int(np.float32(buf[off]) * np.float32(255))
+        assert list(out[h * w - off]) == [v, v, v, 255]
+    # width < height: offsets beyond the buffer are skipped (the reference reads out of bounds)
+    out = vv.slice_to_bgra(np.ones(8, np.float32), 4, 2, fill=9)
+    written = {8 - (j * 4 + i) for j in range(4) for i in range(2) if 0 < j * 4 + i < 8}
+    for k in range(8):
+        assert (list(out[k]) == [255, 255, 255, 255]) == (k in written)
+
+
 def test_no_gpu_means_loud_failure():
     """Without a HIP device the product must fail, not fall back to a CPU path."""
     import torch

@@ -310,6 +310,32 @@ static VolumeView view_of(const vv_context *c)
 // ---- ray march: runCuda, kernel.cu:388-453 ----------------------------------------
 static inline float vlen_h(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
 
+// camera basis of the analytic ray source (shared by vv_render and vv_first_pass)
+static int camera_basis(vv_context *c, FrameParams &P, const camera_params *cam, const vv_ray_source *rays, int W, int H)
+{
+    // camera.cpp:78-91 look-at basis, float
+    float lx = rays->look[0], ly = rays->look[1], lz = rays->look[2];
+    float ll = vlen_h(lx, ly, lz);
+    if (!(ll > 0.f)) return fail(c, VV_ERR_INVALID, "vv_render: look vector is zero");
+    lx /= ll; ly /= ll; lz /= ll;
+    float ux = rays->up[0], uy = rays->up[1], uz = rays->up[2];
+    float sx = ly * uz - lz * uy, sy = lz * ux - lx * uz, sz = lx * uy - ly * ux;
+    float sl = vlen_h(sx, sy, sz);
+    if (!(sl > 0.f)) return fail(c, VV_ERR_INVALID, "vv_render: up vector is parallel to look");
+    sx /= sl; sy /= sl; sz /= sl;
+    float vx = sy * lz - sz * ly, vy = sz * lx - sx * lz, vz = sx * ly - sy * lx;
+    float vl = vlen_h(vx, vy, vz);
+    vx /= vl; vy /= vl; vz /= vl;
+    P.look[0] = lx; P.look[1] = ly; P.look[2] = lz;
+    P.side[0] = sx; P.side[1] = sy; P.side[2] = sz;
+    P.up[0] = vx; P.up[1] = vy; P.up[2] = vz;
+    float aspect = rays->aspect > 0.f ? rays->aspect : (float)W / (float)H;
+    float th = (float)tan((double)cam->fovY * M_PI / 360.0);
+    P.tan_half_x = th * aspect; P.tan_half_y = th;
+    return VV_OK;
+}
+
+
 int vv_render(vv_context *c, int W, int H, const slice_params *slice, const camera_params *cam,
               const shading_params *shading, const vv_ray_source *rays, const vv_render_options *opts,
               uint8_t *rgba_out, int out_on_device, void *stream)
@@ -398,25 +424,8 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     P.tan_fov_y = (float)tan((double)cam->fovY * M_PI / (double)(180.f * (float)(unsigned)H));
     P.ray_mode = rays->mode; P.quantize8 = rays->quantize8;
     if (rays->mode == VV_RAYS_ANALYTIC) {
-        // camera.cpp:78-91 look-at basis, float
-        float lx = rays->look[0], ly = rays->look[1], lz = rays->look[2];
-        float ll = vlen_h(lx, ly, lz);
-        if (!(ll > 0.f)) return fail(c, VV_ERR_INVALID, "vv_render: look vector is zero");
-        lx /= ll; ly /= ll; lz /= ll;
-        float ux = rays->up[0], uy = rays->up[1], uz = rays->up[2];
-        float sx = ly * uz - lz * uy, sy = lz * ux - lx * uz, sz = lx * uy - ly * ux;
-        float sl = vlen_h(sx, sy, sz);
-        if (!(sl > 0.f)) return fail(c, VV_ERR_INVALID, "vv_render: up vector is parallel to look");
-        sx /= sl; sy /= sl; sz /= sl;
-        float vx = sy * lz - sz * ly, vy = sz * lx - sx * lz, vz = sx * ly - sy * lx;
-        float vl = vlen_h(vx, vy, vz);
-        vx /= vl; vy /= vl; vz /= vl;
-        P.look[0] = lx; P.look[1] = ly; P.look[2] = lz;
-        P.side[0] = sx; P.side[1] = sy; P.side[2] = sz;
-        P.up[0] = vx; P.up[1] = vy; P.up[2] = vz;
-        float aspect = rays->aspect > 0.f ? rays->aspect : (float)W / (float)H;
-        float th = (float)tan((double)cam->fovY * M_PI / 360.0);
-        P.tan_half_x = th * aspect; P.tan_half_y = th;
+        int brc = camera_basis(c, P, cam, rays, W, H);
+        if (brc) return brc;
     } else {
         const size_t ib = (size_t)rays->img_w * rays->img_h * 4;
         P.img_w = rays->img_w; P.img_h = rays->img_h;
@@ -501,6 +510,41 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     } else if (!stream) {
         HIPCHK(c, hipStreamSynchronize(st));
     }
+    return VV_OK;
+}
+
+// ---- first pass images ------------------------------------------------------------------
+int vv_first_pass(vv_context *c, int W, int H, const camera_params *cam, const vv_ray_source *rays,
+                  uint8_t *front, uint8_t *back, int out_on_device, void *stream)
+{
+    if (!c) return fail(nullptr, VV_ERR_INVALID, "vv_first_pass: NULL context");
+    if (!cam || !rays || !front || !back || W < 1 || H < 1) return fail(c, VV_ERR_INVALID, "vv_first_pass: bad argument");
+    if (rays->mode != VV_RAYS_ANALYTIC) return fail(c, VV_ERR_INVALID, "vv_first_pass: needs an analytic ray source");
+    for (int a = 0; a < 3; ++a)
+        if (!(cam->scale[a] > 0.f) || !std::isfinite(cam->scale[a])) return fail(c, VV_ERR_INVALID, "vv_first_pass: camera scale must be finite and > 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    FrameParams P;
+    memset(&P, 0, sizeof P);
+    P.W = W; P.H = H;
+    for (int a = 0; a < 3; ++a) { P.cam_pos[a] = cam->origin[a]; P.scale[a] = cam->scale[a]; }
+    int rc = camera_basis(c, P, cam, rays, W, H);
+    if (rc) return rc;
+    const size_t ib = (size_t)W * H * 4;
+    uint8_t *df = front, *db = back;
+    if (!out_on_device) {
+        rc = ensure(c, (void **)&c->d_img, &c->img_cap, 2 * ib);
+        if (rc) return rc;
+        df = c->d_img; db = c->d_img + ib;
+    }
+    if (((uintptr_t)df & 3) || ((uintptr_t)db & 3)) return fail(c, VV_ERR_INVALID, "vv_first_pass: images must be 4-byte aligned");
+    launch_first_pass(P, (uint32_t *)df, (uint32_t *)db, st);
+    HIPCHK(c, hipGetLastError());
+    if (!out_on_device) {
+        HIPCHK(c, hipMemcpyAsync(front, df, ib, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(back, db, ib, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    } else if (!stream) HIPCHK(c, hipStreamSynchronize(st));
     return VV_OK;
 }
 

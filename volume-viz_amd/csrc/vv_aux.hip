@@ -76,6 +76,53 @@ void launch_slice(const SliceArgs &a, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------
+// first pass images (firstpass.vert:6 / firstpass.frag:4 through the analytic ray source)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void first_pass_kernel(FrameParams P, uint32_t *__restrict__ front, uint32_t *__restrict__ back)
+{
+#pragma clang fp contract(off)
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= P.W || y >= P.H) return;
+    // same arithmetic as ray_endpoints (analytic), plus the visibility of each face
+    float ndx = (2.0f * ((float)x + 0.5f)) / (float)P.W - 1.0f;
+    float ndy = (2.0f * ((float)y + 0.5f)) / (float)P.H - 1.0f;
+    float sx = ndx * P.tan_half_x, sy = ndy * P.tan_half_y;
+    float d[3], o[3] = {P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]};
+    for (int a = 0; a < 3; a++) d[a] = (P.side[a] * sx + P.up[a] * sy) + P.look[a];
+    float tmin = -INFINITY, tmax = INFINITY;
+    bool miss = false;
+    for (int a = 0; a < 3; a++) {
+        float s = P.scale[a];
+        if (d[a] != 0.0f) {
+            float t1 = (-s - o[a]) / d[a], t2 = (s - o[a]) / d[a];
+            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+        } else if (o[a] < -s || o[a] > s) miss = true;
+    }
+    uint32_t f = 0u, b = 0u;
+    if (!(miss || !(tmin <= tmax) || !(tmax > 0.0f))) {
+        auto enc = [&](float t) {
+            uint32_t v = 0xff000000u;
+            for (int a = 0; a < 3; a++) {
+                float c = (o[a] + d[a] * t) * 0.5f + 0.5f;
+                c = fmaxf(0.f, fminf(c, 1.f));
+                v |= (uint32_t)floorf(c * 255.0f + 0.5f) << (8 * a);
+            }
+            return v;
+        };
+        b = enc(tmax);
+        if (tmin > 0.0f) f = enc(tmin);
+    }
+    front[(size_t)y * P.W + x] = f;
+    back[(size_t)y * P.W + x] = b;
+}
+
+void launch_first_pass(const FrameParams &P, uint32_t *front, uint32_t *back, hipStream_t s)
+{
+    dim3 grid((P.W + 15) / 16, (P.H + 15) / 16);
+    hipLaunchKernelGGL(first_pass_kernel, grid, dim3(256), 0, s, P, front, back);
+}
+
+// ---------------------------------------------------------------------------
 // generator
 // ---------------------------------------------------------------------------
 struct EllipsoidSet {

@@ -79,6 +79,55 @@ int vv_slice_matrix(float dx, float dy, float dz, float theta, float phi, float 
     return VV_OK;
 }
 
+// GLWidget::setSliceCanonical, glwidget.cpp:757-776
+int vv_cut_plane_canonical(int orientation, float displace, float point[3], float normal[3])
+{
+    if (!point || !normal) return VV_ERR_INVALID;
+    point[0] = point[1] = point[2] = 0.f; normal[0] = normal[1] = normal[2] = 0.f;
+    switch (orientation) {
+    case VV_HORIZONTAL: normal[1] = 1.f; point[1] = displace; return VV_OK;
+    case VV_SAGITTAL:   normal[2] = 1.f; point[2] = displace; return VV_OK;
+    case VV_CORONAL:    normal[0] = 1.f; point[0] = displace; return VV_OK;
+    default: return VV_ERR_INVALID;         // the reference's switch leaves the plane as it was
+    }
+}
+
+// glwidget.cpp:232-258: slice_params marshalling
+int vv_cut_plane_to_slice_params(int slice_type, const float point[3], const float normal[3],
+                                 int flip_cross_section, struct slice_params *out)
+{
+    if (!out) return VV_ERR_INVALID;
+    out->type = slice_type;
+    for (int i = 0; i < 6; ++i) out->params[i] = 0.f;
+    if (slice_type == SLICE_NONE) return VV_OK;
+    if (slice_type != SLICE_PLANE && slice_type != SLICE_PLANE_CUT) return VV_ERR_INVALID;
+    if (!point || !normal) return VV_ERR_INVALID;
+    float n[3] = {normal[0], normal[1], normal[2]};
+    const bool neg = flip_cross_section ? ((double)n[1] < -1e-6) : ((double)n[1] > 1e-6);
+    if (neg) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    for (int i = 0; i < 3; ++i) { out->params[i] = point[i]; out->params[3 + i] = n[i]; }
+    return VV_OK;
+}
+
+// slicewidget.cpp:108-121
+int vv_slice_to_bgra(const float *slice, size_t height, size_t width, uint8_t *bgra)
+{
+    if (!slice || !bgra || height == 0 || width == 0) return VV_ERR_INVALID;
+    const size_t size = width * height;
+    for (size_t j = 0; j < height; ++j)
+        for (size_t i = 0; i < width; ++i) {
+            const size_t offset = j * height + i;                  // :114 (height as stride)
+            if (offset >= size) continue;                           // the reference reads out of bounds here
+            const float f = slice[offset] * 255;
+            const unsigned val = f > 0.f ? (f >= 4294967040.f ? 0xffffffffu : (unsigned)f) : 0u;   // (unsigned)(f*255)
+            const size_t dst = size - offset;                       // :116 mirrored
+            if (dst >= size) continue;                              // offset 0 -> one past the end in the reference
+            uint8_t *p = bgra + 4 * dst;
+            p[0] = p[1] = p[2] = (uint8_t)val; p[3] = 255;          // BGRA(val,val,val,255), CS123Common.h:24-27
+        }
+    return VV_OK;
+}
+
 // header-less files are 128 x 256 x 256 (volumegenerator.cpp:204-208)
 int vv_t3d_read_header(const char *path, int header, int *nx, int *ny, int *nz)
 {

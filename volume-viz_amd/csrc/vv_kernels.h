@@ -40,6 +40,7 @@ struct SliceArgs {
     float trans[16]; int advanced;
 };
 void launch_slice(const SliceArgs &a, hipStream_t s);
+void launch_first_pass(const FrameParams &P, uint32_t *front, uint32_t *back, hipStream_t s);
 
 void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
                                 const float *centers, const float *axes, const uint8_t *colors,

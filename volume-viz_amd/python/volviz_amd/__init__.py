@@ -65,6 +65,7 @@ EXPORTS = [
     "vv_promote_u8_to_f32", "vv_generate_noise_u8", "vv_transfer_preset",
     "vv_t3d_read_header", "vv_t3d_read", "vv_t3d_write", "vv_last_frame_ms",
     "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid", "vv_debug_counters",
+    "vv_first_pass", "vv_cut_plane_canonical", "vv_cut_plane_to_slice_params", "vv_slice_to_bgra",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
 ]
 
@@ -110,6 +111,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_last_frame_ms.argtypes = [vp]; lib.vv_last_frame_ms.restype = f
     lib.vv_last_sample_count.argtypes = [vp]; lib.vv_last_sample_count.restype = C.c_ulonglong
     lib.vv_slice_matrix.argtypes = [f, f, f, f, f, f, vp]
+    lib.vv_first_pass.argtypes = [vp, i, i, C.POINTER(camera_params), C.POINTER(vv_ray_source), vp, vp, i, vp]
+    lib.vv_cut_plane_canonical.argtypes = [i, f, vp, vp]
+    lib.vv_cut_plane_to_slice_params.argtypes = [i, vp, vp, i, C.POINTER(slice_params)]
+    lib.vv_slice_to_bgra.argtypes = [vp, sz, sz, vp]
     lib.vv_debug_counters.argtypes = [vp, vp]
     lib.vv_volume_dims.argtypes = [vp, C.POINTER(i * 3), C.POINTER(i)]
     for name in EXPORTS:
@@ -306,6 +311,13 @@ class Context:
                                      C.byref(options) if options is not None else None,
                                      out_ptr, 1, stream))
 
+    def first_pass(self, img_w: int, img_h: int, cam: Camera):
+        """vv_first_pass: the two RGBA8 FBO images of glwidget.cpp:200-228 for this camera."""
+        front = np.zeros((img_h, img_w, 4), np.uint8); back = np.zeros((img_h, img_w, 4), np.uint8)
+        cp = cam.params(img_w, img_h); rs = analytic_rays(cam)
+        self._chk(self.lib.vv_first_pass(self.h, img_w, img_h, C.byref(cp), C.byref(rs), front.ctypes.data, back.ctypes.data, 0, None))
+        return front, back
+
     def last_frame_ms(self) -> float:
         return float(self.lib.vv_last_frame_ms(self.h))
 
@@ -368,6 +380,35 @@ class Context:
 
     def promote_device(self, dev_in: int, dev_out: int, n: int, stream: int = 0):
         self._chk(self.lib.vv_promote_u8_to_f32(self.h, dev_in, dev_out, n, stream))
+
+
+def cut_plane_canonical(orientation: int, displace: float):
+    """vv_cut_plane_canonical: GLWidget::setSliceCanonical (glwidget.cpp:743-788)."""
+    pt = np.zeros(3, np.float32); n = np.zeros(3, np.float32)
+    rc = load_library().vv_cut_plane_canonical(orientation, displace, pt.ctypes.data, n.ctypes.data)
+    if rc:
+        raise VolvizError(rc, "bad orientation")
+    return pt, n
+
+
+def cut_plane_to_slice_params(slice_type: int, point, normal, flip: bool = False) -> slice_params:
+    """vv_cut_plane_to_slice_params: glwidget.cpp:232-258."""
+    sp = slice_params()
+    pt = np.ascontiguousarray(point, np.float32); n = np.ascontiguousarray(normal, np.float32)
+    rc = load_library().vv_cut_plane_to_slice_params(slice_type, pt.ctypes.data, n.ctypes.data, int(flip), C.byref(sp))
+    if rc:
+        raise VolvizError(rc, "bad slice type")
+    return sp
+
+
+def slice_to_bgra(buf: np.ndarray, height: int, width: int, fill: int = 0) -> np.ndarray:
+    """vv_slice_to_bgra: the image SliceWidget shows (slicewidget.cpp:108-121)."""
+    buf = np.ascontiguousarray(buf, np.float32)
+    out = np.full((height * width, 4), fill, np.uint8)
+    rc = load_library().vv_slice_to_bgra(buf.ctypes.data, height, width, out.ctypes.data)
+    if rc:
+        raise VolvizError(rc, "bad argument")
+    return out
 
 
 def slice_matrix(dx, dy, dz, theta, phi, psi) -> np.ndarray:
