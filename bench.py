@@ -170,6 +170,8 @@ def main():
     samples_all, bytes_all = float(tot[0]), float(tot[1])
 
     # ---- warm-up, then the timed region ----
+    if world > 1:
+        gather()          # opens the point-to-point channels even when --warmup 0
     for _ in range(args.warmup):
         one_frame(opts)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]

@@ -258,6 +258,10 @@ __device__ __forceinline__ void load_rows(const char *b00, uint32_t row_bytes, u
     const char *b11 = b01 + row_bytes;
     if constexpr (VOXEL == VV_VOXEL_F32) {
         const uint32_t off = ix * 4u + yz;
+#ifdef VV_X_NOLOAD
+        // experiment build (tools/decompose.sh): keep the address arithmetic, drop the gathers
+        { float f = __uint_as_float((off & 0xffffu) | 0x3a000000u); C.a = {f, f}; C.b = C.a; C.c = C.a; C.d = C.a; return; }
+#endif
         C.a = *(const float2u *)(b00 + off); C.b = *(const float2u *)(b10 + off);
         C.c = *(const float2u *)(b01 + off); C.d = *(const float2u *)(b11 + off);
     } else {

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
     const bool in_frame = x <= xmax && y <= ymax && row_owned(P, y);
 
     float res_r = 0.f, res_g = 0.f, res_b = 0.f, res_a = 0.f;
-    unsigned long long executed = 0;
+    unsigned long long executed = 0, slots = 0;
     bool write_zero = false;
 
     Ray r;
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         for (int bit = 16; bit > 0; bit >>= 1)
             if (__any(n >= (nmax | bit))) nmax |= bit;
         bool stop = false;
+        if (INSTR) slots += (unsigned long long)((nmax + U - 1) / U * U) * 64ull;   // lane slots this wave spends
         // U samples per trip: their gathers are all issued before the first is consumed.  With
         // the block count per CU capped (lds_reserve) registers are plentiful and the extra
         // loads in flight pay.
@@ -183,6 +184,17 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                 fetch_corners<VOXEL, TEX8, kBig>(V, tx[u], ty[u], tz[u], C[u]);
             }
             __builtin_amdgcn_sched_barrier(0);           // all 4U gathers are issued before the first is consumed
+#ifdef VV_X_NOALU
+            // experiment build (tools/decompose.sh): keep the gathers, drop classification and blending
+            if constexpr (VOXEL == VV_VOXEL_F32) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float v = ((C[u].a.x + C[u].b.x) + (C[u].c.x + C[u].d.x)) + ((C[u].a.y + C[u].b.y) + (C[u].c.y + C[u].d.y));
+                    res_r += (i0 + u <= n) ? v * 1e-30f : 0.f;
+                }
+                continue;
+            }
+#endif
             uint32_t idx[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) idx[u] = classify_index<VOXEL>(C[u], tx[u], ty[u], tz[u]);
@@ -236,6 +248,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
     if (INSTR) {
         for (int o = 32; o > 0; o >>= 1) executed += __shfl_down(executed, o);
         if (lane == 0 && executed) atomicAdd(counter, executed);
+        if (lane == 0 && slots) atomicAdd(counter + 1, slots);      // developer statistic: lane utilisation
     }
 }
 
