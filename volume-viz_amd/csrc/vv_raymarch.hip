@@ -270,8 +270,12 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
     __shared__ float4 lds_tf[256];
     __shared__ float red[256];
     __shared__ uint8_t cache[kCacheDepth][256];
+    __shared__ float q255[256];              // q / 255.f for every byte q, by the same IEEE division
     __shared__ int any_live;
     stage_tf(lds_tf, tf);
+    // kernel.cu:175-177 divides six cached bytes by 255.f per shaded sample; a correctly rounded
+    // division is ~10 instructions, a table look-up of the same quotient is one LDS read
+    q255[threadIdx.x] = (float)threadIdx.x / 255.f;      // visible after the barriers of the reduction below
 
     // blockIdx.y -> slab row of this shard; the last grid row is the "extra" slab row
     // nby-1 that re-writes pixel row H-2 when H == 1 (mod 14) (pin 10): it travels with
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
                     // all three central differences zero (inside a plateau): the gradient is (0,0,0),
                     // it is not normalised (:180) and direct = clamp(0) = 0 -- skip the divisions
                     if (!(qr == ql && qt == qb && qa == qf)) {
-                        float f = qf / 255.f, a = qa / 255.f, l = ql / 255.f, rr = qr / 255.f, t = qt / 255.f, b = qb / 255.f;
+                        float f = q255[qf], a = q255[qa], l = q255[ql], rr = q255[qr], t = q255[qt], b = q255[qb];
                         float gx = (rr - l) / (P.tan_fov_x * vd), gy = (t - b) / (P.tan_fov_y * vd),
                               gz = (a - f) / (r.sstep * 2.f);                         // :175-178, :259-263
                         if (gx != 0.f && gy != 0.f && gz != 0.f) {
