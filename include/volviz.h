@@ -210,6 +210,27 @@ int  vv_cut_plane_canonical(int orientation, float displace, float point[3], flo
 int  vv_cut_plane_to_slice_params(int slice_type, const float point[3], const float normal[3],
                                   int flip_cross_section, struct slice_params *out);
 
+/* Camera / cutting-plane controls of the 3D view (host-only arithmetic, no device work).
+ * The reference does these with Qt 4 value types (float-stored QVector3D read back as qreal,
+ * double QMatrix4x4) inside its mouse handlers; Qt is not available to pin them bit for bit, so
+ * they are restated in double precision on float inputs/outputs and tested to 1e-5.
+ *   vv_camera_orbit_drag    right-button drag (glwidget.cpp:432-446): spherical orbit about the
+ *                           origin, theta clamped to [0.1, pi-0.1], look re-aimed at the origin
+ *   vv_camera_zoom          wheel (glwidget.cpp:607-620): position += look * delta/200
+ *   vv_cut_plane_from_drag  left-button drag released (glwidget.cpp:482-535): the plane through the
+ *                           eye ray of the release point and the near-plane point of the press
+ *                           point; window coordinates are fractions of the widget (y down);
+ *                           point comes back in cube space [0,1]^3, normal un-normalised as in
+ *                           the reference; perspective(45 deg, aspect, 0.1, 100) (glwidget.cpp:338)
+ *   vv_cut_plane_drag       middle-button drag of such a plane (glwidget.cpp:447-452)          */
+int  vv_camera_orbit_drag(const float position[3], int dx, int dy, float out_position[3], float out_look[3]);
+int  vv_camera_zoom(const float position[3], const float look[3], int delta, float out_position[3]);
+int  vv_cut_plane_from_drag(const float position[3], const float look[3], const float up[3], float aspect,
+                            const float press[2], const float release[2],
+                            float point[3], float normal[3], float plane_up[3], float plane_right[3]);
+int  vv_cut_plane_drag(float point[3], const float plane_up[3], const float plane_right[3],
+                       int dx, int dy, int width, int height);
+
 /* Slice buffer -> the BGRA image SliceWidget shows (slicewidget.cpp:108-121): grey value
  * (unsigned)(f*255), alpha 255, written mirrored at bits[size - offset] with offset = j*height+i;
  * bits[0] and elements whose index falls outside stay untouched.  bgra: width*height*4 bytes. */

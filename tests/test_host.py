@@ -136,3 +136,63 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
                 txt = open(os.path.join(root, f), errors="ignore").read()
                 assert "vvo_" not in txt and "libvvoracle" not in txt and "libvvref" not in txt, os.path.join(root, f)
+
+
+def _qt_perspective(fov_deg, aspect, n, f):
+    c = 1.0 / np.tan(np.radians(fov_deg) / 2.0)
+    return np.array([[c / aspect, 0, 0, 0], [0, c, 0, 0], [0, 0, -(f + n) / (f - n), -2 * f * n / (f - n)], [0, 0, -1, 0]])
+
+
+def _camera_transform(pos, look, up):
+    look = look / np.linalg.norm(look)
+    side = np.cross(look, up); side /= np.linalg.norm(side)
+    upv = np.cross(side, look); upv /= np.linalg.norm(upv)
+    R = np.eye(4); R[0, :3] = side; R[1, :3] = upv; R[2, :3] = -look
+    T = np.eye(4); T[:3, 3] = -pos
+    return R @ T                                              # camera.cpp:78-91
+
+
+def test_camera_controls_match_matrix_form():
+    """glwidget.cpp:426-535, 607-620 restated independently here with 4x4 matrices in double."""
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        pos = rng.normal(size=3) * 3 + np.array([0.3, 0.2, -4.0])
+        dx, dy = int(rng.integers(-300, 300)), int(rng.integers(-300, 300))
+        p2, look2 = vv.camera_orbit_drag(pos, dx, dy)
+        pf = pos.astype(np.float32).astype(np.float64)
+        r = np.linalg.norm(pf)
+        theta = np.clip(np.arccos(pf[1] / r) - dy / 200.0, 0.1, np.pi - 0.1)
+        phi = np.arctan2(pf[2], pf[0]) + dx / 200.0
+        want = r * np.array([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)])
+        assert np.allclose(p2, want, rtol=0, atol=2e-5 * max(1.0, r))
+        assert np.allclose(look2, -want / np.linalg.norm(want), atol=1e-5)
+        assert abs(np.linalg.norm(p2) - r) < 1e-4                       # the orbit keeps the radius
+
+        look = -pos / np.linalg.norm(pos)
+        assert np.allclose(vv.camera_zoom(pos, look, 120), pos + look * 0.6, atol=1e-5)
+        assert np.array_equal(vv.camera_zoom(pos, look, 0), pos.astype(np.float32))
+
+        aspect = float(rng.uniform(0.8, 2.0))
+        press, release = rng.uniform(0.1, 0.9, size=2), rng.uniform(0.1, 0.9, size=2)
+        up = np.array([0.0, 1.0, 0.0])
+        pt, n, pu, pr = vv.cut_plane_from_drag(pos, look, up, aspect, press, release)
+        f32 = lambda v: np.asarray(v, np.float32).astype(np.float64)
+        inv = np.linalg.inv(_qt_perspective(45.0, f32(aspect), 0.1, 100.0) @ _camera_transform(f32(pos), f32(look), up))
+        glc = lambda v: v * 2.0 - 1.0
+        pr_, rl_ = f32(press), f32(release)
+        front = inv @ np.array([glc(rl_[0]), -glc(rl_[1]), -1.0, 1.0]); front /= front[3]
+        back = inv @ np.array([glc(rl_[0]), -glc(rl_[1]), 1.0, 1.0]); back /= back[3]
+        side = inv @ np.array([glc(pr_[0]), -glc(pr_[1]), -1.0, 1.0]); side /= side[3]
+        a = (back - front); a /= np.linalg.norm(a)
+        b = (side - front); b /= np.linalg.norm(b)
+        assert np.allclose(pt, (front[:3] + 1.0) / 2.0, atol=1e-5)
+        assert np.allclose(n, np.cross(a[:3], b[:3]), atol=2e-4)     # far-plane point amplifies rounding
+        assert np.allclose(pu, (inv @ np.array([0.0, -1.0, 0.0, 0.0]))[:3], atol=1e-5)
+        assert np.allclose(pr, (inv @ np.array([1.0, 0.0, 0.0, 0.0]))[:3], atol=1e-5)
+        # the plane contains the eye ray of the release point and the pressed near-plane point
+        assert abs(np.dot(n, back[:3] - front[:3])) < 1e-2 and abs(np.dot(n, side[:3] - front[:3])) < 1e-4
+
+        moved = vv.cut_plane_drag(pt, pu, pr, dx, dy, 1920, 1080)
+        assert np.allclose(moved, pt + pr * dx / 1920 * 3.5 + pu * dy / 1080 * 3.5, atol=1e-5)
+    with pytest.raises(vv.VolvizError):
+        vv.camera_orbit_drag((0, 0, 0), 1, 1)

@@ -109,6 +109,89 @@ int vv_cut_plane_to_slice_params(int slice_type, const float point[3], const flo
     return VV_OK;
 }
 
+// ---- camera / cutting-plane controls (glwidget.cpp:426-535, 607-620); double arithmetic ----
+namespace {
+struct V3 { double x, y, z; };
+inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 normalized(V3 a) { double l = std::sqrt(dot(a, a)); return l > 0 ? V3{a.x / l, a.y / l, a.z / l} : a; }
+inline V3 ld(const float *p) { return {p[0], p[1], p[2]}; }
+inline void st(float *p, V3 v) { p[0] = (float)v.x; p[1] = (float)v.y; p[2] = (float)v.z; }
+} // namespace
+
+int vv_camera_orbit_drag(const float position[3], int dx, int dy, float out_position[3], float out_look[3])
+{
+    if (!position || !out_position) return VV_ERR_INVALID;
+    const V3 p = ld(position);
+    const float r = (float)std::sqrt(dot(p, p));
+    if (!(r > 0.f)) return VV_ERR_INVALID;
+    float theta = (float)(std::acos(p.y / r) - dy / 200.f);                 // :436-438
+    const float phi = (float)(std::atan2(p.z, p.x) + dx / 200.f);
+    if (theta < 0.1f) theta = 0.1f;                                          // :440-444
+    if (theta > M_PI - 0.1f) theta = (float)(M_PI - 0.1f);
+    const V3 q = {r * std::sin((double)theta) * std::cos((double)phi), r * std::cos((double)theta),
+                  r * std::sin((double)theta) * std::sin((double)phi)};     // :446
+    st(out_position, q);
+    if (out_look) st(out_look, normalized(sub({0, 0, 0}, ld(out_position))));   // camera->lookAt(origin), camera.cpp:27
+    return VV_OK;
+}
+
+int vv_camera_zoom(const float position[3], const float look[3], int delta, float out_position[3])
+{
+    if (!position || !look || !out_position) return VV_ERR_INVALID;
+    const double k = delta / 200.f;                                          // :615
+    for (int i = 0; i < 3; ++i) out_position[i] = delta ? (float)(position[i] + look[i] * k) : position[i];
+    return VV_OK;
+}
+
+int vv_cut_plane_from_drag(const float position[3], const float look_[3], const float up_[3], float aspect,
+                           const float press[2], const float release[2],
+                           float point[3], float normal[3], float plane_up[3], float plane_right[3])
+{
+    if (!position || !look_ || !up_ || !press || !release || !point || !normal || !(aspect > 0.f)) return VV_ERR_INVALID;
+    // camera frame of Camera::lazyComputeTransform (camera.cpp:78-91): rows side, up, -look
+    const V3 eye = ld(position), look = normalized(ld(look_));
+    const V3 side = normalized(cross(look, ld(up_))), up = normalized(cross(side, look));
+    // inverse of perspective(45, aspect, .1, 100) * view applied to NDC points (x, y, z, 1):
+    // eye-space point of NDC (x, y, z) is (x*a*t, y*t, -1) * w', w' = 1 / ((z*(n-f) + (f+n)) / (2fn))
+    const double n = 0.1, f = 100.0, t = std::tan(45.0 * M_PI / 360.0);
+    auto unproject = [&](double x, double y, double z) -> V3 {
+        const double w = (2.0 * f * n) / ((f + n) - z * (f - n));           // distance along -z_eye
+        const double ex = x * aspect * t * w, ey = y * t * w;
+        return {eye.x + side.x * ex + up.x * ey + look.x * w,
+                eye.y + side.y * ex + up.y * ey + look.y * w,
+                eye.z + side.z * ex + up.z * ey + look.z * w};
+    };
+    auto glc = [](double v) { return v * 2.0 - 1.0; };                        // :85-88
+    const V3 front = unproject(glc(release[0]), -glc(release[1]), -1.0);     // :491-495
+    const V3 back  = unproject(glc(release[0]), -glc(release[1]),  1.0);
+    const V3 sidep = unproject(glc(press[0]),   -glc(press[1]),   -1.0);
+    const V3 a = normalized(sub(back, front)), b = normalized(sub(sidep, front));   // :503-504
+    const V3 nrm_ = cross(a, b);                                             // :507-510 (not normalised)
+    point[0] = (float)((front.x + 1.0) / 2.0);                               // :512-514, nrm() :90-93
+    point[1] = (float)((front.y + 1.0) / 2.0);
+    point[2] = (float)((front.z + 1.0) / 2.0);
+    st(normal, nrm_);
+    // inverse * (0,-1,0,0) and inverse * (1,0,0,0): directions; the projection scales them by
+    // tan(fov/2) (and the aspect) before the camera rotation carries them to world space (:497-498)
+    if (plane_up)    st(plane_up,    {-up.x * t, -up.y * t, -up.z * t});
+    if (plane_right) st(plane_right, {side.x * aspect * t, side.y * aspect * t, side.z * aspect * t});
+    return VV_OK;
+}
+
+int vv_cut_plane_drag(float point[3], const float plane_up[3], const float plane_right[3],
+                      int dx, int dy, int width, int height)
+{
+    if (!point || !plane_up || !plane_right || width <= 0 || height <= 0) return VV_ERR_INVALID;
+    for (int i = 0; i < 3; ++i) {                                            // :448-449
+        double p = point[i] + (double)plane_right[i] * dx / width * 3.5;
+        p = (float)p + (double)plane_up[i] * dy / height * 3.5;
+        point[i] = (float)p;
+    }
+    return VV_OK;
+}
+
 // slicewidget.cpp:108-121
 int vv_slice_to_bgra(const float *slice, size_t height, size_t width, uint8_t *bgra)
 {

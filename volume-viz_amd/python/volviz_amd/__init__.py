@@ -66,6 +66,7 @@ EXPORTS = [
     "vv_t3d_read_header", "vv_t3d_read", "vv_t3d_write", "vv_last_frame_ms",
     "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid", "vv_debug_counters",
     "vv_first_pass", "vv_cut_plane_canonical", "vv_cut_plane_to_slice_params", "vv_slice_to_bgra",
+    "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
 ]
 
@@ -115,6 +116,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_cut_plane_canonical.argtypes = [i, f, vp, vp]
     lib.vv_cut_plane_to_slice_params.argtypes = [i, vp, vp, i, C.POINTER(slice_params)]
     lib.vv_slice_to_bgra.argtypes = [vp, sz, sz, vp]
+    lib.vv_camera_orbit_drag.argtypes = [vp, i, i, vp, vp]
+    lib.vv_camera_zoom.argtypes = [vp, vp, i, vp]
+    lib.vv_cut_plane_from_drag.argtypes = [vp, vp, vp, f, vp, vp, vp, vp, vp, vp]
+    lib.vv_cut_plane_drag.argtypes = [vp, vp, vp, i, i, i, i]
     lib.vv_debug_counters.argtypes = [vp, vp]
     lib.vv_volume_dims.argtypes = [vp, C.POINTER(i * 3), C.POINTER(i)]
     for name in EXPORTS:
@@ -399,6 +404,51 @@ def cut_plane_to_slice_params(slice_type: int, point, normal, flip: bool = False
     if rc:
         raise VolvizError(rc, "bad slice type")
     return sp
+
+
+def _f3(v) -> np.ndarray:
+    return np.ascontiguousarray(v, np.float32).reshape(3).copy()
+
+
+def camera_orbit_drag(position, dx: int, dy: int):
+    """vv_camera_orbit_drag: right-button drag (glwidget.cpp:432-446) -> (position, look)."""
+    p = _f3(position); out = np.zeros(3, np.float32); look = np.zeros(3, np.float32)
+    rc = load_library().vv_camera_orbit_drag(p.ctypes.data, dx, dy, out.ctypes.data, look.ctypes.data)
+    if rc:
+        raise VolvizError(rc, "camera at the origin")
+    return out, look
+
+
+def camera_zoom(position, look, delta: int) -> np.ndarray:
+    """vv_camera_zoom: wheel (glwidget.cpp:607-620)."""
+    p = _f3(position); l = _f3(look); out = np.zeros(3, np.float32)
+    rc = load_library().vv_camera_zoom(p.ctypes.data, l.ctypes.data, delta, out.ctypes.data)
+    if rc:
+        raise VolvizError(rc, "bad argument")
+    return out
+
+
+def cut_plane_from_drag(position, look, up, aspect: float, press, release):
+    """vv_cut_plane_from_drag: left-button drag released (glwidget.cpp:482-535)
+    -> (point, normal, plane_up, plane_right)."""
+    p = _f3(position); l = _f3(look); u = _f3(up)
+    a = np.ascontiguousarray(press, np.float32).reshape(2).copy()
+    b = np.ascontiguousarray(release, np.float32).reshape(2).copy()
+    out = [np.zeros(3, np.float32) for _ in range(4)]
+    rc = load_library().vv_cut_plane_from_drag(p.ctypes.data, l.ctypes.data, u.ctypes.data, aspect, a.ctypes.data,
+                                               b.ctypes.data, *[o.ctypes.data for o in out])
+    if rc:
+        raise VolvizError(rc, "bad argument")
+    return tuple(out)
+
+
+def cut_plane_drag(point, plane_up, plane_right, dx: int, dy: int, width: int, height: int) -> np.ndarray:
+    """vv_cut_plane_drag: middle-button drag of an image plane (glwidget.cpp:447-452)."""
+    p = _f3(point); u = _f3(plane_up); r = _f3(plane_right)
+    rc = load_library().vv_cut_plane_drag(p.ctypes.data, u.ctypes.data, r.ctypes.data, dx, dy, width, height)
+    if rc:
+        raise VolvizError(rc, "bad argument")
+    return p
 
 
 def slice_to_bgra(buf: np.ndarray, height: int, width: int, fill: int = 0) -> np.ndarray:
