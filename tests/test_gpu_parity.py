@@ -269,6 +269,77 @@ def test_render_quantised_analytic(ctx):
     assert_frames_close(got, want)
 
 
+def _random_case(seed):
+    """One seeded configuration of everything vv_render takes."""
+    rng = np.random.default_rng(1000 + seed)
+    dims = tuple(int(v) for v in rng.integers(5, 48, size=3))                     # nx, ny, nz
+    kind = seed % 3
+    if kind == 0:
+        vol = O.draw_default_brain(*dims)
+    elif kind == 1:
+        vol = O.noise_u8(*dims, int(rng.integers(1, 2**31)))
+    else:
+        vol = rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)               # white noise: worst case for ERT order
+    if rng.random() < 0.5:
+        vol = vol.astype(np.float32) / np.float32(255)
+        if rng.random() < 0.3:
+            vol = (vol * np.float32(1.3) - np.float32(0.1)).astype(np.float32)     # values outside [0,1]: saturating index
+    if rng.random() < 0.5:
+        tf = vv.transfer_preset(int(rng.choice([vv.TF_ENGINE, vv.TF_HEAD, vv.TF_MRI])))
+    else:
+        tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
+        tf[:, 3] *= np.float32(rng.choice([0.03, 0.2, 1.0]))
+        tf[: int(rng.integers(0, 60)), 3] = 0
+    W = int(rng.choice([int(rng.integers(2, 90)), 29, 43, 57, 71]))               # incl. W == 1 (mod 14)
+    H = int(rng.choice([int(rng.integers(2, 90)), 29, 43, 57]))
+    scale = tuple(float(v) for v in rng.choice([1.0, 1.0, 0.8, 1.57, 0.5], size=3))
+    r = float(rng.uniform(1.2, 5.0))
+    cam = vv.Camera.orbit(r, float(rng.uniform(0.15, np.pi - 0.15)), float(rng.uniform(-np.pi, np.pi)), scale=scale)
+    st = int(rng.choice([vv.SLICE_NONE, vv.SLICE_PLANE, vv.SLICE_PLANE_CUT]))
+    point = rng.uniform(0.2, 0.8, size=3); normal = rng.normal(size=3)
+    sp = vv.make_slice_params(st, tuple(point), tuple(normal))
+    step = None if rng.random() < 0.4 else float(rng.choice([1 / 16, 1 / 37, 1 / 64, 1 / 130]))
+    opts = dict(step=step, filter=int(rng.choice([vv.FILTER_TEX8, vv.FILTER_EXACT])),
+                ert_mode=int(rng.choice([vv.ERT_REFERENCE, vv.ERT_TRUE])),
+                ert_threshold=float(rng.choice([0.95, 0.5, 0.999])), count_samples=True)
+    return vol, tf, W, H, cam, sp, bool(rng.random() < 0.4), opts
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_render_random_sweep(ctx, seed):
+    """Seeded sweep over volume shape/type/content, table, frame size, camera, scale, cutting plane,
+    step, filter, ERT mode and threshold, shading: every frame bit-identical to the oracle."""
+    vol, tf, W, H, cam, sp, phong, o = _random_case(seed)
+    ctx.load_volume(vol, tf)
+    opts = vv.make_options(**o)
+    got = ctx.render(W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
+    want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
+    assert_frames_close(got, want, f"seed {seed}: {vol.shape} {vol.dtype} {W}x{H} phong={phong} {o}")
+    assert ctx.last_sample_count() == n
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_slice_random_sweep(ctx, seed):
+    rng = np.random.default_rng(7000 + seed)
+    dims = tuple(int(v) for v in rng.integers(3, 40, size=3))
+    vol = rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)
+    if seed % 2:
+        vol = vol.astype(np.float32) / np.float32(255)
+    ctx.load_volume(vol, vv.transfer_preset(vv.TF_HEAD))
+    h, w = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+    scale = tuple(float(v) for v in rng.choice([1.0, 0.8, 1.57], size=3))
+    filt = int(rng.choice([vv.FILTER_TEX8, vv.FILTER_EXACT]))
+    for orient in (vv.SAGITTAL, vv.CORONAL, vv.HORIZONTAL):
+        d = [float(v) for v in rng.uniform(-0.3, 0.3, size=3)]
+        got = ctx.slice(h, w, *d, orientation=orient, scale=scale, filter=filt, fill=-1.0)
+        want = O.slice(vol, h, w, *d, orientation=orient, scale=scale, filter=filt, fill=-1.0)
+        assert np.array_equal(got, want), (seed, orient)
+    m = O.slice_matrix(*[float(v) for v in rng.uniform(-0.4, 0.4, size=3)], *[float(v) for v in rng.uniform(-3.1, 3.1, size=3)])
+    got = ctx.slice_advanced(h, w, m, scale=scale, filter=filt, fill=-1.0)
+    want = O.slice_advanced(vol, h, w, m, scale=scale, filter=filt, fill=-1.0)
+    assert np.array_equal(got, want), seed
+
+
 @pytest.mark.parametrize("W,H", [(1, 1), (1, 9), (9, 1), (2, 2), (14, 14), (15, 16), (16, 15)])
 def test_render_tiny_frames(ctx, W, H):
     vol = O.draw_default_brain(8, 8, 8)
