@@ -129,25 +129,29 @@ def main():
                 shard=sharding.shard_option(world, rank))
     opts = vv.make_options(**base)
 
-    hp = sharding.padded_height(H, world)
-    frame = torch.zeros((hp, W, 4), dtype=torch.uint8, device=dev)
-    recv = None
-    if world > 1 and rank == 0:
-        recv = [torch.empty_like(sharding.compact(frame, world, 0)) for _ in range(world)]
+    # Frames are double-buffered: the gather of frame k (one RCCL collective) overlaps the
+    # march of frame k+1; VV_BENCH_SYNC_GATHER=1 waits for each gather before the next frame instead.
+    G = sharding.FrameGatherer(H, W, world, rank, device=dev)
+    sync_gather = share or os.environ.get("VV_BENCH_SYNC_GATHER") == "1"
+    frame = G.frames[0]
 
-    def gather():
+    def submit(b):
+        if world == 1:
+            return
         if not share:
-            return sharding.gather_frame(frame, world, rank, recv)
-        torch.cuda.synchronize()
-        out = sharding.gather_frame(frame.cpu(), world, rank)
+            G.submit(b)
+            if sync_gather:
+                G.finish(b)
+            return
+        torch.cuda.synchronize()                 # rehearsal on one GPU: gloo on host copies
+        out = sharding.gather_frame(G.frames[b].cpu(), world, rank)
         if rank == 0:
-            frame.copy_(out)
-        return out
+            G.frames[b].copy_(out)
 
-    def one_frame(o):
-        ctx.render_device(W, H, cam, frame.data_ptr(), options=o, stream=stream, phong=args.phong)
-        if world > 1:
-            gather()
+    def one_frame(o, b=0):
+        G.finish(b)
+        ctx.render_device(W, H, cam, G.frames[b].data_ptr(), options=o, stream=stream, phong=args.phong)
+        submit(b)
 
     # ---- untimed instrumented pass: executed samples + bricks touched (byte model) ----
     nb = (n + BRICK - 1) // BRICK
@@ -171,24 +175,28 @@ def main():
 
     # ---- warm-up, then the timed region ----
     if world > 1:
-        gather()          # opens the point-to-point channels even when --warmup 0
-    for _ in range(args.warmup):
-        one_frame(opts)
+        one_frame(opts, 0); one_frame(opts, 1)      # opens the point-to-point channels even when --warmup 0
+    for k in range(args.warmup):
+        one_frame(opts, k & 1)
+    G.drain()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        b = k & 1
+        G.finish(b)
         ev[k][0].record()
-        ctx.render_device(W, H, cam, frame.data_ptr(), options=opts, stream=stream, phong=args.phong)
+        ctx.render_device(W, H, cam, G.frames[b].data_ptr(), options=opts, stream=stream, phong=args.phong)
         ev[k][1].record()
-        if world > 1:
-            gather()
+        submit(b)
+    G.drain()                                        # every frame is complete on rank 0 inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
+    frame = G.frames[(args.steps - 1) & 1]
     el = torch.tensor([t1 - t0], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)

@@ -64,3 +64,47 @@ def test_band_bookkeeping():
             assert sharding.padded_height(H, world) >= H
     f = torch.arange(2 * 56 * 3 * 4, dtype=torch.uint8).reshape(2 * 56, 3, 4)
     assert torch.equal(sharding.compact(f, 2, 1)[0], f[56:112])
+
+
+def _stream_worker(rank, world, port, W, H, n_frames, q):
+    """bench.py's frame loop with FrameGatherer: frame k is 'rendered' as a function of (k, row)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = sharding.FrameGatherer(H, W, world, rank)
+    rows = sharding.owned_rows(H, world, rank)
+    done = []
+    for k in range(n_frames):
+        b = k & 1
+        f = g.finish(b)
+        if rank == 0 and f is not None:
+            done.append(f[:H].clone().numpy())
+        g.frames[b][rows] = torch.tensor([[(k * 37 + y) % 251 for _ in range(4)] for y in rows], dtype=torch.uint8)[:, None, :]
+        g.submit(b)
+    order = [(n_frames - 2 + i) & 1 for i in range(2)] if n_frames >= 2 else [0]
+    for b in order:                                     # oldest outstanding frame first
+        f = g.finish(b)
+        if rank == 0 and f is not None:
+            done.append(f[:H].clone().numpy())
+    if rank == 0:
+        q.put(done)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 5), (3, 4), (2, 1)])
+def test_async_double_buffered_gather(world, n_frames):
+    W, H = 9, 130
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, W, H, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    done = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(done) == n_frames
+    for k, f in enumerate(done):
+        want = np.array([[(k * 37 + y) % 251] * 4 for y in range(H)], np.uint8)[:, None, :].repeat(W, axis=1)
+        assert np.array_equal(f, want), k

@@ -58,3 +58,56 @@ def gather_frame(frame_padded: torch.Tensor, world: int, rank: int, recv=None, g
         return frame_padded
     dist.gather(mine, gather_list=None, dst=0, group=group)
     return None
+
+
+class FrameGatherer:
+    """Double-buffered, asynchronous form of gather_frame for a stream of frames: the gather of
+    frame k runs (on the collective's own stream, over xGMI) while frame k+1 is being rendered
+    into the other buffer.  Per step:
+
+        g.finish(b)          # frame that used buffer b two steps ago is complete on rank 0
+        render into g.frames[b] (owned rows only)
+        g.submit(b)          # send this rank's bands, do not wait
+
+    and g.drain() after the last step.  Nothing is exchanged while a frame is marched; this only
+    moves the one collective per frame off the critical path.  Buffers are allocated once."""
+
+    def __init__(self, height: int, width: int, world: int, rank: int, device=None, depth: int = 2, group=None):
+        self.world, self.rank, self.group = world, rank, group
+        hp = padded_height(height, world)
+        self.frames = [torch.zeros((hp, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
+        nb = hp // BAND_PX // world
+        self.mine = [torch.empty((nb, BAND_PX, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.recv = [[torch.empty_like(self.mine[0]) for _ in range(world)] if (rank == 0 and world > 1) else None
+                     for _ in range(depth)]
+        self.work = [None] * depth
+
+    def submit(self, b: int) -> None:
+        if self.world == 1:
+            return
+        assert self.work[b] is None, "finish(b) first"
+        f = self.frames[b]
+        hp, w, c = f.shape
+        self.mine[b].copy_(f.view(hp // BAND_PX, BAND_PX, w, c)[self.rank::self.world])
+        self.work[b] = dist.gather(self.mine[b], gather_list=self.recv[b], dst=0, group=self.group, async_op=True)
+
+    def finish(self, b: int):
+        """Waits for the gather submitted on buffer b (if any); on rank 0 writes the other ranks'
+        bands back at their rows and returns the assembled padded frame."""
+        if self.world == 1:
+            return self.frames[b]
+        if self.work[b] is None:
+            return None
+        self.work[b].wait()              # the current stream now orders after the collective
+        self.work[b] = None
+        if self.rank != 0:
+            return None
+        f = self.frames[b]
+        hp, w, c = f.shape
+        out = f.view(hp // BAND_PX, BAND_PX, w, c)
+        for r in range(1, self.world):
+            out[r::self.world] = self.recv[b][r]
+        return f
+
+    def drain(self):
+        return [self.finish(b) for b in range(len(self.frames))]
