@@ -430,6 +430,42 @@ def test_staged_kernel_is_bit_identical(ctx, view, monkeypatch):
     assert ctx.debug_counters()[1] > 0
 
 
+@pytest.mark.parametrize("seed", range(0, 48, 3))
+def test_bricked_copy_is_bit_identical(ctx, seed, monkeypatch):
+    """The 4x4x4-brick copy of the volume (used by default for views off the memory axis on volumes
+    of 64 MiB and more) forced on the sweep's small volumes: same frames, same sample counts."""
+    monkeypatch.setenv("VV_BRICKED", "1")
+    vol, tf, W, H, cam, sp, phong, o = _random_case(seed)
+    ctx.load_volume(vol, tf)
+    opts = vv.make_options(**o)
+    got = ctx.render(W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
+    n_got = ctx.last_sample_count()
+    ran_bricked = ctx.debug_counters()[2] > 0
+    want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
+    assert_frames_close(got, want, f"bricked seed {seed}: {vol.shape} {vol.dtype} phong={phong}")
+    assert n_got == n and (ran_bricked or n == 0)
+
+
+def test_bricked_copy_edges_and_reload(ctx, monkeypatch):
+    """Volume edges not multiples of the brick size (incl. single-voxel axes), both voxel types,
+    and the copy is rebuilt when another volume is loaded."""
+    monkeypatch.setenv("VV_BRICKED", "1")
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    cam = _cam("b")
+    rng = np.random.default_rng(3)
+    for dims in ((1, 1, 1), (4, 4, 4), (5, 4, 3), (3, 9, 1), (8, 7, 13), (17, 16, 15)):
+        for dtype in (np.uint8, np.float32):
+            vol = rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)
+            if dtype == np.float32:
+                vol = vol.astype(np.float32) / np.float32(255)
+            ctx.load_volume(vol, tf)
+            for phong in (False, True):
+                got = ctx.render(61, 47, cam, phong=phong, options=vv.make_options(step=1 / 40, count_samples=True))
+                want, n = O.render(vol, tf, 61, 47, cam, phong=phong, options=vv.make_options(step=1 / 40))
+                assert_frames_close(got, want, f"bricked {dims} {np.dtype(dtype).name} phong={phong}")
+                assert ctx.last_sample_count() == n
+
+
 def test_render_full_size_properties(ctx):
     """BASELINE config C2 size (256^3 f32, 1280x720): size-independent properties instead of
     a full oracle frame -- (1) a 3-slab-row band of the oracle matches, (2) the frame equals the
@@ -521,7 +557,7 @@ def test_big_volume_addressing_forced(ctx, monkeypatch):
         assert np.array_equal(ctx.slice_advanced(64, 64, m), O.slice_advanced(vol, 64, 64, m))
 
 
-def test_volume_above_4gib(ctx):
+def test_volume_above_4gib(ctx, monkeypatch):
     """A real volume larger than 4 GiB (1280^3 f32 = 8.4 GB, generated on the device): a band of
     the frame against the oracle on the downloaded volume, and shard re-assembly."""
     import torch
@@ -543,17 +579,24 @@ def test_volume_above_4gib(ctx):
     W, H = 640, 360
     cam = _cam("b")
     opts = vv.make_options(step=1 / 320, count_samples=True)
-    full = ctx.render(W, H, cam, options=opts)
-    n_full = ctx.last_sample_count()
     band = (11, 14)
-    want = np.zeros_like(full)
-    _, n_band = O.render(host, tf, W, H, cam, options=vv.make_options(step=1 / 320, slab_rows=band), out=want)
-    rows = slice(band[0] * 14, band[1] * 14)
-    assert_frames_close(full[rows], want[rows], "8.4 GB volume band")
-    assert (full[rows][..., 3] > 0).mean() > 0.2
-    got_band = np.zeros_like(full)
-    ctx.render(W, H, cam, options=vv.make_options(step=1 / 320, slab_rows=band, count_samples=True), out=got_band)
-    assert ctx.last_sample_count() == n_band and n_band < n_full
+    want = None
+    # this camera is off the memory axis: by default the bricked copy (10.5 GB) is sampled, through
+    # 64-bit layer addressing; VV_BRICKED=0 takes the linear layout with its 64-bit slice bases
+    for bricked in ("1", "0"):
+        monkeypatch.setenv("VV_BRICKED", bricked)
+        full = ctx.render(W, H, cam, options=opts)
+        n_full = ctx.last_sample_count()
+        assert (ctx.debug_counters()[2] > 0) == (bricked == "1")
+        if want is None:
+            want = np.zeros_like(full)
+            _, n_band = O.render(host, tf, W, H, cam, options=vv.make_options(step=1 / 320, slab_rows=band), out=want)
+        rows = slice(band[0] * 14, band[1] * 14)
+        assert_frames_close(full[rows], want[rows], f"8.4 GB volume band, bricked={bricked}")
+        assert (full[rows][..., 3] > 0).mean() > 0.2
+        got_band = np.zeros_like(full)
+        ctx.render(W, H, cam, options=vv.make_options(step=1 / 320, slab_rows=band, count_samples=True), out=got_band)
+        assert ctx.last_sample_count() == n_band and n_band < n_full
     # free the 8.4 GB volume for the tests that follow
     ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
 

@@ -24,6 +24,8 @@ struct vv_context {
     bool timed = false;
     // volume
     void *d_vol = nullptr; size_t vol_bytes = 0; int vtype = VV_VOXEL_U8; int nx = 0, ny = 0, nz = 0;
+    // bricked copy of an f32 volume for views off the memory axis (built on first use, dropped on reload)
+    void *d_bricks = nullptr; bool bricks_valid = false; uint32_t b_sy = 0, b_sz64 = 0;
     // transfer function
     float4 *d_tf = nullptr; bool tf_gray = false; bool have_tf = false;
     // scratch
@@ -50,6 +52,12 @@ static int fail(vv_context *c, int code, const std::string &msg)
 }
 #define HIPCHK(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
     return fail((c), VV_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+static void drop_bricks(vv_context *c)
+{
+    if (c->d_bricks) (void)hipFree(c->d_bricks);
+    c->d_bricks = nullptr; c->bricks_valid = false;
+}
 
 static int ensure(vv_context *c, void **p, size_t *cap, size_t need)
 {
@@ -94,6 +102,7 @@ int vv_shutdown(vv_context *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (c->d_vol) hipFree(c->d_vol);
+    drop_bricks(c);
     if (c->d_tf) hipFree(c->d_tf);
     if (c->d_rad) hipFree(c->d_rad);
     if (c->d_frame) hipFree(c->d_frame);
@@ -145,6 +154,7 @@ static int install_volume(vv_context *c, const void *src, bool src_on_device, in
     // one slice + one row + 16 bytes of zero padding: weight-0 corner fetches of edge
     // samples land here instead of needing index clamps (see vv_device.h VolumeView)
     const size_t pad = (size_t)nx * ny * vsz + (size_t)nx * vsz + 16;
+    drop_bricks(c);
     if (c->d_vol) { HIPCHK(c, hipFree(c->d_vol)); c->d_vol = nullptr; }   // the reference leaks here
     HIPCHK(c, hipMalloc(&c->d_vol, bytes + pad));
     hipStream_t st = s ? s : c->stream;
@@ -196,6 +206,7 @@ int vv_load_volume_stream_begin(vv_context *c, int vtype, int nx, int ny, int nz
         return fail(c, VV_ERR_INVALID, "stream_begin: a volume row must be below 16 MiB and each dimension below 2^24");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)nx * ny * nz * vsz, pad = (size_t)nx * ny * vsz + (size_t)nx * vsz + 16;
+    drop_bricks(c);
     if (c->d_vol) { HIPCHK(c, hipFree(c->d_vol)); c->d_vol = nullptr; }
     HIPCHK(c, hipMalloc(&c->d_vol, bytes + pad));
     if (!c->copy_stream) HIPCHK(c, hipStreamCreate(&c->copy_stream));
@@ -304,6 +315,7 @@ static VolumeView view_of(const vv_context *c)
     V.row_bytes = (uint32_t)c->nx * vsz;
     V.slice_bytes = (uint32_t)c->nx * (uint32_t)c->ny * vsz;
     V.big = c->vol_bytes > (1ull << 32) || V.slice_bytes >= (1u << 24) || getenv("VV_FORCE_BIG") != nullptr;
+    V.bricks = nullptr; V.b_sy = 0; V.b_sz64 = 0;
     return V;
 }
 
@@ -463,6 +475,31 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     A.lds_reserve = !beyond_caches ? 49000 : (A.strips.tile_log2w == 5 ? 76000 : 155000);
     if (const char *e = getenv("VV_UNROLL")) { int t = atoi(e); if (t == 2 || t == 3) A.unroll = t; }
     if (const char *e = getenv("VV_LDS_RESERVE")) { int t = atoi(e); if (t >= 0 && t <= 155 * 1024) A.lds_reserve = t; }
+    // Bricked copy (speed only): off the memory axis the linear layout costs one cache line per lane
+    // and gather; 4x4x4 bricks keep a wave's footprint in a few dozen lines.  both voxel types, both kernels;
+    // built on first use if HBM has room (1.25x an f32 volume, 2x a u8 volume).  VV_BRICKED=0/1 overrides the policy.
+    bool use_bricks = A.strips.tile_log2w == 3 && c->vol_bytes >= (c->vtype == VV_VOXEL_F32 ? (64ull << 20) : (16ull << 20));
+    if (const char *e = getenv("VV_BRICKED")) use_bricks = atoi(e) != 0;
+    if (use_bricks && !c->bricks_valid) {
+        uint32_t sy = 0, sz64 = 0;
+        const size_t bb = brick_copy_bytes(c->vtype, c->nx, c->ny, c->nz, &sy, &sz64);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bb + (512ull << 20) || sz64 >= (1u << 24) ||
+            hipMalloc(&c->d_bricks, bb + 16) != hipSuccess) {
+            (void)hipGetLastError(); c->d_bricks = nullptr; use_bricks = false;      // no room: linear path
+        } else {
+            launch_build_bricks(c->vtype, c->d_vol, c->d_bricks, c->nx, c->ny, c->nz, st);
+            HIPCHK(c, hipMemsetAsync((char *)c->d_bricks + bb, 0, 16, st));
+            HIPCHK(c, hipStreamSynchronize(st));      // later frames may come on another stream
+            c->b_sy = sy; c->b_sz64 = sz64; c->bricks_valid = true;
+        }
+    }
+    if (use_bricks) {
+        A.V.bricks = c->d_bricks; A.V.b_sy = c->b_sy; A.V.b_sz64 = c->b_sz64;
+        // measured (C3 rotated, 1024^3): 2 blocks per CU and 2 samples per trip: 3.64 -> 1.60 ms
+        if (!getenv("VV_UNROLL")) A.unroll = 2;
+        if (!getenv("VV_LDS_RESERVE")) A.lds_reserve = beyond_caches ? 76000 : 49000;
+    }
     A.lds_reserve_phong = beyond_caches ? 40000 : 20000;    // 3 / 4 blocks per CU (measured: 3.02 -> 2.68 ms on C3 + Phong)
     if (const char *e = getenv("VV_LDS_RESERVE_PHONG")) { int t = atoi(e); if (t >= 0 && t <= 146 * 1024) A.lds_reserve_phong = t; }
     A.gray = c->tf_gray; A.phong = shading->phongShading;
@@ -488,7 +525,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     c->counter_valid = A.instr;
     HIPCHK(c, hipEventRecord(c->ev0, st));
     if (A.phong) {
-        if (A.V.big) launch_raymarch_big(A, st); else launch_raymarch(A, st);
+        if (A.V.bricks) launch_raymarch_bricked(A, st); else if (A.V.big) launch_raymarch_big(A, st); else launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
         // Wave-private LDS brick cache (vv_raymarch_wstaged.hip): bit-identical to march_kernel
@@ -498,6 +535,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         bool wst = false;
         if (const char *e = getenv("VV_WSTAGED")) wst = atoi(e) != 0 && (A.V.row_bytes % 16u) == 0 && !A.V.big;
         if (wst) launch_raymarch_wstaged(A, st);
+        else if (A.V.bricks) launch_raymarch_bricked(A, st);
         else if (A.V.big) launch_raymarch_big(A, st);
         else launch_raymarch(A, st);
     }

@@ -38,7 +38,20 @@ struct VolumeView {
     uint32_t row_bytes;     // nx * sizeof(voxel)
     uint32_t slice_bytes;   // nx*ny * sizeof(voxel)
     int big;                // volume > 4 GiB or slice >= 16 MiB: 64-bit slice base per sample (BIG kernels)
+    // Optional second copy in 4x4x4-voxel bricks for views that are not aligned with the x axis
+    // (built on first use, vv_api.cpp).  A brick is 16 rows (y fastest, then z) of 4 voxels + 1 halo
+    // voxel (= the next voxel in x, clamped): f32 rows are 20 bytes (brick 320 B), u8 rows are padded
+    // to 8 bytes (brick 128 B = one cache line).  Bricks are x fastest.  The grid has one extra brick
+    // layer in y and z when needed so that y+1 / z+1 always exist (clamped content), which keeps
+    // the sampler free of index clamps like the linear layout.
+    const void *bricks;
+    uint32_t b_sy;          // bytes per row of bricks   (nbx * brick bytes)
+    uint32_t b_sz64;        // bytes per layer of bricks (nby * b_sy) in 64-byte units
 };
+template <int VOXEL> struct BrickGeom;
+template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t brick = 320, row = 20; };
+template <> struct BrickGeom<VV_VOXEL_U8>  { static constexpr uint32_t brick = 128, row = 8; };
+enum { LAYOUT_LINEAR = 0, LAYOUT_LINEAR_BIG = 1, LAYOUT_BRICKED = 2 };
 
 // Everything a frame needs that is uniform over the launch.
 struct FrameParams {
@@ -277,7 +290,7 @@ __device__ __forceinline__ void load_rows(const char *b00, uint32_t row_bytes, u
 }
 
 // texture coordinates -> weights + loads in flight (no use of the loaded data)
-template <int VOXEL, bool TEX8, bool BIG = false>
+template <int VOXEL, bool TEX8, int LAYOUT = LAYOUT_LINEAR>
 __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, float py, float pz, Corners<VOXEL> &C)
 {
     uint32_t ix, iy, iz;
@@ -285,16 +298,43 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
     C.wy = axis_coord<TEX8>(py, (float)V.ny, (float)(V.ny - 1), iy);
     C.wz = axis_coord<TEX8>(pz, (float)V.nz, (float)(V.nz - 1), iz);
     // row/slice offsets: 24-bit multiplies are full rate (v_mul_lo_u32 is quarter rate); indices
-    // and row_bytes are always < 2^24; volumes whose slice_bytes is not take the BIG path.  BIG is a
-    // compile-time choice: a run-time branch here cost 4 % (view along z) to 23 % (rotated view).
-    if (!BIG) {
+    // and row_bytes are always < 2^24; volumes whose slice_bytes is not take the BIG path.  The layout
+    // is a compile-time choice: a run-time branch here cost 4 % (view along z) to 23 % (rotated view).
+    if constexpr (LAYOUT == LAYOUT_LINEAR) {
         // up to 4 GiB: one 32-bit byte offset per sample added to four scalar bases (saddr + voffset)
         load_rows<VOXEL>((const char *)V.data, V.row_bytes, V.slice_bytes, ix,
                          __umul24(iy, V.row_bytes) + __umul24(iz, V.slice_bytes), C);
-    } else {
+    } else if constexpr (LAYOUT == LAYOUT_LINEAR_BIG) {
         // volumes above 4 GiB (separate kernel instantiations): 64-bit slice base per lane
         const char *zb = (const char *)V.data + (uint64_t)iz * V.slice_bytes;
         load_rows<VOXEL>(zb, V.row_bytes, V.slice_bytes, ix, __umul24(iy, V.row_bytes), C);
+    } else {
+        // bricked copy: the rows y / y+1 and the slices z / z+1 of a sample sit in the same brick
+        // unless (y & 3) == 3 resp. (z & 3) == 3; the x pair always does (halo voxel)
+        using G = BrickGeom<VOXEL>;
+        const uint32_t ya = iy & 3u, za = iz & 3u;
+        const uint32_t oy0 = __umul24(iy >> 2, V.b_sy) + __umul24(ya, G::row);
+        const uint32_t oy1 = oy0 + (ya == 3u ? V.b_sy - 3u * G::row : G::row);
+        const uint32_t m0  = __umul24(iz >> 2, V.b_sz64);                 // layer offset, 64-byte units
+        const uint32_t m1  = m0 + (za == 3u ? V.b_sz64 : 0u);
+        const uint32_t zi0 = __umul24(za, 4u * G::row), zi1 = za == 3u ? 0u : zi0 + 4u * G::row;
+        const char *L0 = (const char *)V.bricks + ((uint64_t)m0 << 6);
+        const char *L1 = (const char *)V.bricks + ((uint64_t)m1 << 6);
+        if constexpr (VOXEL == VV_VOXEL_F32) {
+            const uint32_t ox = __umul24(ix >> 2, G::brick) + ((ix & 3u) << 2);
+            const uint32_t o0 = ox + oy0, o1 = ox + oy1;
+            C.a = *(const float2u *)(L0 + (o0 + zi0)); C.b = *(const float2u *)(L0 + (o1 + zi0));
+            C.c = *(const float2u *)(L1 + (o0 + zi1)); C.d = *(const float2u *)(L1 + (o1 + zi1));
+        } else {
+            // the whole 8-byte row (voxels 4*(x>>2) .. +4, then padding) in one aligned load;
+            // finish_corners shifts voxel x to byte 0 exactly as for the linear layout
+            const uint32_t ox = (ix >> 2) * G::brick;
+            const uint32_t o0 = ox + oy0, o1 = ox + oy1;
+            C.sh = ix & 3u;
+            const uint2 ra = *(const uint2 *)(L0 + (o0 + zi0)), rb = *(const uint2 *)(L0 + (o1 + zi0));
+            const uint2 rc = *(const uint2 *)(L1 + (o0 + zi1)), rd = *(const uint2 *)(L1 + (o1 + zi1));
+            C.a0 = ra.x; C.a1 = ra.y; C.b0 = rb.x; C.b1 = rb.y; C.c0 = rc.x; C.c1 = rc.y; C.d0 = rd.x; C.d1 = rd.y;
+        }
     }
 }
 
@@ -327,7 +367,7 @@ template <int VOXEL, bool TEX8, bool BIG = false>
 __device__ __forceinline__ float tex3d_raw(const VolumeView &V, float px, float py, float pz)
 {
     Corners<VOXEL> C;
-    fetch_corners<VOXEL, TEX8, BIG>(V, px, py, pz, C);
+    fetch_corners<VOXEL, TEX8, BIG ? LAYOUT_LINEAR_BIG : LAYOUT_LINEAR>(V, px, py, pz, C);
     return finish_corners<VOXEL>(C);
 }
 
@@ -355,7 +395,7 @@ template <int VOXEL, bool TEX8, bool BIG = false>
 __device__ __forceinline__ uint32_t sample_index(const VolumeView &V, float px, float py, float pz)
 {
     Corners<VOXEL> C;
-    fetch_corners<VOXEL, TEX8, BIG>(V, px, py, pz, C);
+    fetch_corners<VOXEL, TEX8, BIG ? LAYOUT_LINEAR_BIG : LAYOUT_LINEAR>(V, px, py, pz, C);
     return classify_index<VOXEL>(C, px, py, pz);
 }
 

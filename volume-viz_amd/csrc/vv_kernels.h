@@ -30,6 +30,9 @@ struct MarchArgs {
 void launch_rad(const MarchArgs &a, hipStream_t s);
 void launch_raymarch(const MarchArgs &a, hipStream_t s);
 void launch_raymarch_big(const MarchArgs &a, hipStream_t s);      // same kernels, volumes above 4 GiB
+void launch_raymarch_bricked(const MarchArgs &a, hipStream_t s);  // same kernels on VolumeView::bricks
+size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_t *sz64);
+void launch_build_bricks(int vtype, const void *linear, void *bricks, int nx, int ny, int nz, hipStream_t s);
 void launch_raymarch_wstaged(const MarchArgs &a, hipStream_t s);  // wave-private LDS brick cache (no Phong)
 
 struct SliceArgs {

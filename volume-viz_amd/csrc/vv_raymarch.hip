@@ -15,14 +15,18 @@
 #include "vv_device.h"
 #include "vv_kernels.h"
 
-// This file is compiled twice: as is (volumes up to 4 GiB) and through vv_raymarch_big.hip with
-// VV_BIG_VOLUME defined (64-bit slice addressing), so that the common path pays nothing for it.
-#ifdef VV_BIG_VOLUME
+// This file is compiled three times: as is (linear volume up to 4 GiB), through vv_raymarch_big.hip
+// with VV_BIG_VOLUME (linear, 64-bit slice addressing) and through vv_raymarch_brick.hip with
+// VV_BRICKED (volume sampled from the bricked copy), so that each path pays only for itself.
+#if defined(VV_BRICKED)
+#define VV_BIG_NS brick
+constexpr int kLayout = vv::LAYOUT_BRICKED;
+#elif defined(VV_BIG_VOLUME)
 #define VV_BIG_NS big
-constexpr bool kBig = true;
+constexpr int kLayout = vv::LAYOUT_LINEAR_BIG;
 #else
 #define VV_BIG_NS small
-constexpr bool kBig = false;
+constexpr int kLayout = vv::LAYOUT_LINEAR;
 #endif
 
 namespace vv {
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                 tx[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
                 ty[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
                 tz[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-                fetch_corners<VOXEL, TEX8, kBig>(V, tx[u], ty[u], tz[u], C[u]);
+                fetch_corners<VOXEL, TEX8, kLayout>(V, tx[u], ty[u], tz[u], C[u]);
             }
             __builtin_amdgcn_sched_barrier(0);           // all 4U gathers are issued before the first is consumed
 #ifdef VV_X_NOALU
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         for (int o = 32; o > 0; o >>= 1) executed += __shfl_down(executed, o);
         if (lane == 0 && executed) atomicAdd(counter, executed);
         if (lane == 0 && slots) atomicAdd(counter + 1, slots);      // developer statistic: lane utilisation
+        if (kLayout == LAYOUT_BRICKED && lane == 0 && executed) atomicAdd(counter + 2, 1ull);   // waves that sampled the bricked copy
     }
 }
 
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
                     tx_[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
                     ty_[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
                     tz_[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-                    fetch_corners<VOXEL, TEX8, kBig>(V, tx_[u], ty_[u], tz_[u], C[u]);
+                    fetch_corners<VOXEL, TEX8, kLayout>(V, tx_[u], ty_[u], tz_[u], C[u]);
                     px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -431,6 +436,7 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
     if (INSTR) {
         for (int o = 32; o > 0; o >>= 1) executed += __shfl_down(executed, o);
         if ((threadIdx.x & 63) == 0 && executed) atomicAdd(counter, executed);
+        if (kLayout == LAYOUT_BRICKED && (threadIdx.x & 63) == 0 && executed) atomicAdd(counter + 2, 1ull);
     }
 }
 
@@ -500,7 +506,9 @@ static void launch_raymarch_impl(const MarchArgs &a, hipStream_t s)
 
 } // namespace VV_BIG_NS
 
-#ifdef VV_BIG_VOLUME
+#if defined(VV_BRICKED)
+void launch_raymarch_bricked(const MarchArgs &a, hipStream_t s) { brick::launch_raymarch_impl(a, s); }
+#elif defined(VV_BIG_VOLUME)
 void launch_raymarch_big(const MarchArgs &a, hipStream_t s) { big::launch_raymarch_impl(a, s); }
 #else
 void launch_rad(const MarchArgs &a, hipStream_t s) { small::launch_rad_impl(a, s); }
