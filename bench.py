@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--volume", default="noise", choices=["noise", "brain"])
     ap.add_argument("--tf", default="ramp", choices=["ramp", "head", "engine"])
     ap.add_argument("--view", default="a", choices=["a", "b"])
+    ap.add_argument("--orbit", default="", help="theta,phi in degrees: camera on the orbit of radius 4 (diagnostic; overrides --view)")
     ap.add_argument("--size", type=int, default=0, help="override the volume edge (debug)")
     ap.add_argument("--voxel", default="f32", choices=["f32", "u8"], help="u8 is a diagnostic variant, not the C3 metric")
     ap.add_argument("--filter", default="tex8", choices=["tex8", "exact"])
@@ -123,6 +124,9 @@ def main():
     torch.cuda.empty_cache()
 
     cam = vv.Camera() if args.view == "a" else vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5)
+    if args.orbit:
+        th, ph = (float(v) for v in args.orbit.split(","))
+        cam = vv.Camera.orbit(4.0, np.radians(th), np.radians(ph))
     step = 1.0 / steps
     base = dict(step=step, filter=vv.FILTER_TEX8 if args.filter == "tex8" else vv.FILTER_EXACT,
                 ert_mode=vv.ERT_REFERENCE if args.ert == "reference" else vv.ERT_TRUE,
@@ -218,7 +222,7 @@ def main():
     pj = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pj):
         try:
-            traffic = json.load(open(pj)).get(f"{args.config}-{args.volume}-{args.tf}-{args.view}-n{world}")
+            traffic = None if args.orbit else json.load(open(pj)).get(f"{args.config}-{args.volume}-{args.tf}-{args.view}-n{world}")
         except Exception:
             traffic = None
     out = {
@@ -227,7 +231,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.voxel, "data": "synthetic",
         "config": {"workload": f"{args.config.upper()}: {n}^3 {args.voxel} {args.volume} volume, {W}x{H}, step 1/{steps}, "
-                               f"{args.tf} RGBA TF, ERT {args.ert}, {args.filter} filter, view {args.view}" + (", Phong" if args.phong else ""),
+                               f"{args.tf} RGBA TF, ERT {args.ert}, {args.filter} filter, view {args.orbit or args.view}" + (", Phong" if args.phong else ""),
                    "volume": [n, n, n], "frame": [W, H], "steps_per_unit_length": steps,
                    "sharding": "single GPU" if world == 1 else f"bands of {sharding.BAND_PX} pixel rows round-robin over {world} GPUs, volume replicated, 1 RCCL gather/frame"},
         "executed_samples_per_frame": int(samples_all), "upper_bound_samples_WxHxS": W * H * steps,
