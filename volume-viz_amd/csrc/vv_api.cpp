@@ -26,6 +26,8 @@ struct vv_context {
     void *d_vol = nullptr; size_t vol_bytes = 0; int vtype = VV_VOXEL_U8; int nx = 0, ny = 0, nz = 0;
     // bricked copy of an f32 volume for views off the memory axis (built on first use, dropped on reload)
     void *d_bricks = nullptr; bool bricks_valid = false; uint32_t b_sy = 0, b_sz64 = 0;
+    // z-pair copy of an f32 volume for views along the memory axis (same life cycle)
+    void *d_zpair = nullptr; bool zpair_valid = false; uint32_t zp_row = 0, zp_slab = 0;
     // transfer function
     float4 *d_tf = nullptr; bool tf_gray = false; bool have_tf = false;
     // scratch
@@ -57,6 +59,8 @@ static void drop_bricks(vv_context *c)
 {
     if (c->d_bricks) (void)hipFree(c->d_bricks);
     c->d_bricks = nullptr; c->bricks_valid = false;
+    if (c->d_zpair) (void)hipFree(c->d_zpair);
+    c->d_zpair = nullptr; c->zpair_valid = false;
 }
 
 static int ensure(vv_context *c, void **p, size_t *cap, size_t need)
@@ -316,6 +320,7 @@ static VolumeView view_of(const vv_context *c)
     V.slice_bytes = (uint32_t)c->nx * (uint32_t)c->ny * vsz;
     V.big = c->vol_bytes > (1ull << 32) || V.slice_bytes >= (1u << 24) || getenv("VV_FORCE_BIG") != nullptr;
     V.bricks = nullptr; V.b_sy = 0; V.b_sz64 = 0;
+    V.zpair = nullptr; V.zp_row_bytes = 0; V.zp_slab_bytes = 0;
     return V;
 }
 
@@ -500,6 +505,30 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         if (!getenv("VV_UNROLL")) A.unroll = 2;
         if (!getenv("VV_LDS_RESERVE")) A.lds_reserve = beyond_caches ? 76000 : 49000;
     }
+    // z-pair copy (speed only): along the memory axis the four corners (x..x+1, z..z+1) of a row come
+    // from one 16-byte gather, so a sample costs 2 gathers instead of 4.  f32 volumes, 2x the volume in
+    // HBM.  Measured on MI355X: -7 % on C1/C2, -10 % on 256^3 at C3's frame, -3 % on 512^3, but +6 % on
+    // 768^3 and +20 % on 1024^3 (rays of different z phase stop sharing slices in L2) and nothing on the
+    // Phong path: used for unshaded frames of volumes up to 512 MiB.  VV_ZPAIR=0/1 overrides.
+    bool use_zpair = !use_bricks && c->vtype == VV_VOXEL_F32 && A.strips.tile_log2w == 5 && !shading->phongShading &&
+                     c->vol_bytes <= (512ull << 20);
+    if (const char *e = getenv("VV_ZPAIR")) use_zpair = atoi(e) != 0 && !use_bricks && c->vtype == VV_VOXEL_F32;
+    if (use_zpair && !c->zpair_valid) {
+        uint32_t rb = 0, sb = 0;
+        const size_t zb = zpair_copy_bytes(c->nx, c->ny, c->nz, &rb, &sb);
+        size_t free_b = 0, total_b = 0;
+        if ((size_t)(c->ny + 1) * ((size_t)c->nx + 1) * 8 >= (1ull << 32) || ((size_t)c->nx + 1) * 8 >= (1u << 24) ||
+            hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < zb + (512ull << 20) ||
+            hipMalloc(&c->d_zpair, zb + 32) != hipSuccess) {
+            (void)hipGetLastError(); c->d_zpair = nullptr; use_zpair = false;
+        } else {
+            launch_build_zpair((const float *)c->d_vol, (float *)c->d_zpair, c->nx, c->ny, c->nz, st);
+            HIPCHK(c, hipMemsetAsync((char *)c->d_zpair + zb, 0, 32, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            c->zp_row = rb; c->zp_slab = sb; c->zpair_valid = true;
+        }
+    }
+    if (use_zpair) { A.V.zpair = c->d_zpair; A.V.zp_row_bytes = c->zp_row; A.V.zp_slab_bytes = c->zp_slab; }
     A.lds_reserve_phong = beyond_caches ? 40000 : 20000;    // 3 / 4 blocks per CU (measured: 3.02 -> 2.68 ms on C3 + Phong)
     if (const char *e = getenv("VV_LDS_RESERVE_PHONG")) { int t = atoi(e); if (t >= 0 && t <= 146 * 1024) A.lds_reserve_phong = t; }
     A.gray = c->tf_gray; A.phong = shading->phongShading;
@@ -525,7 +554,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     c->counter_valid = A.instr;
     HIPCHK(c, hipEventRecord(c->ev0, st));
     if (A.phong) {
-        if (A.V.bricks) launch_raymarch_bricked(A, st); else if (A.V.big) launch_raymarch_big(A, st); else launch_raymarch(A, st);
+        if (A.V.bricks) launch_raymarch_bricked(A, st); else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big) launch_raymarch_big(A, st); else launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
         // Wave-private LDS brick cache (vv_raymarch_wstaged.hip): bit-identical to march_kernel
@@ -536,6 +565,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         if (const char *e = getenv("VV_WSTAGED")) wst = atoi(e) != 0 && (A.V.row_bytes % 16u) == 0 && !A.V.big;
         if (wst) launch_raymarch_wstaged(A, st);
         else if (A.V.bricks) launch_raymarch_bricked(A, st);
+        else if (A.V.zpair) launch_raymarch_zpair(A, st);
         else if (A.V.big) launch_raymarch_big(A, st);
         else launch_raymarch(A, st);
     }

@@ -47,11 +47,20 @@ struct VolumeView {
     const void *bricks;
     uint32_t b_sy;          // bytes per row of bricks   (nbx * brick bytes)
     uint32_t b_sz64;        // bytes per layer of bricks (nby * b_sy) in 64-byte units
+    // Optional z-pair copy of an f32 volume for views along the memory axis (built on first use):
+    // record (x, y, z) = { v(x,y,z), v(x,y,z+1) } (8 bytes), x fastest, rows of nx+1 records, slabs of
+    // ny+1 rows, nz slabs; indices beyond the volume clamp.  The two x-neighbouring records of a row
+    // are the four corners (x..x+1, y, z..z+1) of a sample: one 16-byte gather per row instead of
+    // two 8-byte gathers, i.e. 2 gathers per sample instead of 4 (a wave-wide gather costs the same
+    // 16 cycles for 8 and for 16 bytes per lane).  2x the volume in HBM.
+    const void *zpair;
+    uint32_t zp_row_bytes;  // (nx+1) * 8
+    uint32_t zp_slab_bytes; // (ny+1) * zp_row_bytes
 };
 template <int VOXEL> struct BrickGeom;
 template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t brick = 320, row = 20; };
 template <> struct BrickGeom<VV_VOXEL_U8>  { static constexpr uint32_t brick = 128, row = 8; };
-enum { LAYOUT_LINEAR = 0, LAYOUT_LINEAR_BIG = 1, LAYOUT_BRICKED = 2 };
+enum { LAYOUT_LINEAR = 0, LAYOUT_LINEAR_BIG = 1, LAYOUT_BRICKED = 2, LAYOUT_ZPAIR = 3 };
 
 // Everything a frame needs that is uniform over the launch.
 struct FrameParams {
@@ -338,6 +347,38 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
     }
 }
 
+// ---- z-pair copy (f32): two 16-byte gathers per sample ----
+typedef float __attribute__((ext_vector_type(4), aligned(8))) float4u;    // 8-byte aligned quad
+typedef float __attribute__((ext_vector_type(2))) float2v;
+// naming: c<x><y><z>.  Plain floats (not the loaded vectors) so that the struct stays in registers.
+struct CornersZ { float wx, c000, c001, c100, c101, wy, c010, c011, c110, c111, wz; };
+
+template <bool TEX8>
+__device__ __forceinline__ void fetch_corners_zpair(const VolumeView &V, float px, float py, float pz, CornersZ &C)
+{
+    uint32_t ix, iy, iz;
+    C.wx = axis_coord<TEX8>(px, (float)V.nx, (float)(V.nx - 1), ix);
+    C.wy = axis_coord<TEX8>(py, (float)V.ny, (float)(V.ny - 1), iy);
+    C.wz = axis_coord<TEX8>(pz, (float)V.nz, (float)(V.nz - 1), iz);
+    const char *zb = (const char *)V.zpair + (uint64_t)iz * V.zp_slab_bytes;      // the copy of a 1024^3 volume is 8.6 GB
+    const uint32_t off = __umul24(iy, V.zp_row_bytes) + (ix << 3);
+    const float4u r0 = *(const float4u *)(zb + off);                         // (x, y, z..z+1), (x+1, y, z..z+1)
+    const float4u r1 = *(const float4u *)(zb + off + V.zp_row_bytes);        // the same for y+1
+    C.c000 = r0.x; C.c001 = r0.y; C.c100 = r0.z; C.c101 = r0.w;
+    C.c010 = r1.x; C.c011 = r1.y; C.c110 = r1.z; C.c111 = r1.w;
+}
+
+// same operations as finish_corners (x, then y, then z; fma(w, b - a, a)), two at a time
+__device__ __forceinline__ float finish_corners(const CornersZ &C)
+{
+    const float2v lo0 = {C.c000, C.c001}, hi0 = {C.c100, C.c101}, lo1 = {C.c010, C.c011}, hi1 = {C.c110, C.c111};
+    const float2v wx = {C.wx, C.wx}, wy = {C.wy, C.wy};
+    const float2v cy0 = __builtin_elementwise_fma(wx, hi0 - lo0, lo0);      // (c00, c01)
+    const float2v cy1 = __builtin_elementwise_fma(wx, hi1 - lo1, lo1);      // (c10, c11)
+    const float2v cz  = __builtin_elementwise_fma(wy, cy1 - cy0, cy0);      // (c0, c1)
+    return __builtin_fmaf(C.wz, cz.y - cz.x, cz.x);
+}
+
 // loaded rows -> trilinear value in storage units (0..255 for u8, as-is for f32)
 template <int VOXEL>
 __device__ __forceinline__ float finish_corners(const Corners<VOXEL> &C)
@@ -383,10 +424,13 @@ __device__ __forceinline__ bool bounds_check(float x, float y, float z)
 // kernel.cu:99-105 sample(): (uchar)(0xff * tex3D) or 0 outside.  For u8 volumes the
 // normalisation and the multiplication cancel, the index is trunc(L) (DESIGN.md pin 2);
 // f32 volumes: trunc(255 * L), saturated.
-template <int VOXEL>
-__device__ __forceinline__ uint32_t classify_index(const Corners<VOXEL> &C, float px, float py, float pz)
+template <int VOXEL> __device__ __forceinline__ float corner_value(const Corners<VOXEL> &C) { return finish_corners<VOXEL>(C); }
+template <int VOXEL> __device__ __forceinline__ float corner_value(const CornersZ &C) { return finish_corners(C); }
+
+template <int VOXEL, class CT>
+__device__ __forceinline__ uint32_t classify_index(const CT &C, float px, float py, float pz)
 {
-    float L = finish_corners<VOXEL>(C);
+    float L = corner_value<VOXEL>(C);
     float s = (VOXEL == VV_VOXEL_F32) ? L * 255.0f : L;
     uint32_t idx = min((uint32_t)s, 255u);          // v_cvt_u32_f32 saturates; NaN -> 0
     return bounds_check(px, py, pz) ? idx : 0u;

@@ -15,10 +15,14 @@
 #include "vv_device.h"
 #include "vv_kernels.h"
 
-// This file is compiled three times: as is (linear volume up to 4 GiB), through vv_raymarch_big.hip
-// with VV_BIG_VOLUME (linear, 64-bit slice addressing) and through vv_raymarch_brick.hip with
-// VV_BRICKED (volume sampled from the bricked copy), so that each path pays only for itself.
-#if defined(VV_BRICKED)
+// This file is compiled four times: as is (linear volume up to 4 GiB), through vv_raymarch_big.hip
+// with VV_BIG_VOLUME (linear, 64-bit slice addressing), through vv_raymarch_brick.hip with
+// VV_BRICKED (volume sampled from the bricked copy) and through vv_raymarch_zpair.hip with VV_ZPAIR
+// (f32 volume sampled from the z-pair copy), so that each path pays only for itself.
+#if defined(VV_ZPAIR)
+#define VV_BIG_NS zpair
+constexpr int kLayout = vv::LAYOUT_ZPAIR;
+#elif defined(VV_BRICKED)
 #define VV_BIG_NS brick
 constexpr int kLayout = vv::LAYOUT_BRICKED;
 #elif defined(VV_BIG_VOLUME)
@@ -31,6 +35,22 @@ constexpr int kLayout = vv::LAYOUT_LINEAR;
 
 namespace vv {
 namespace VV_BIG_NS {
+
+// corner registers and fetch of the layout this translation unit is compiled for
+template <int VOXEL> struct CornerSel { using type = Corners<VOXEL>; };
+#ifdef VV_ZPAIR
+template <> struct CornerSel<VV_VOXEL_F32> { using type = CornersZ; };
+#endif
+template <int VOXEL, bool TEX8, class CT>
+__device__ __forceinline__ void fetch_any(const VolumeView &V, float px, float py, float pz, CT &C)
+{
+#ifdef VV_ZPAIR
+    if constexpr (VOXEL == VV_VOXEL_F32) fetch_corners_zpair<TEX8>(V, px, py, pz, C);
+    else fetch_corners<VOXEL, TEX8, LAYOUT_LINEAR>(V, px, py, pz, C);
+#else
+    fetch_corners<VOXEL, TEX8, kLayout>(V, px, py, pz, C);
+#endif
+}
 
 // ---------------------------------------------------------------------------
 // rad pre-pass: one block per slab, one thread per (clamped) footprint pixel.
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         // loads in flight pay.
         for (int i0 = 1; i0 <= nmax; i0 += U) {
             float tx[U], ty[U], tz[U];
-            Corners<VOXEL> C[U];
+            typename CornerSel<VOXEL>::type C[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;      // :141 (sample i = i increments)
@@ -185,10 +205,10 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                 tx[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
                 ty[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
                 tz[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-                fetch_corners<VOXEL, TEX8, kLayout>(V, tx[u], ty[u], tz[u], C[u]);
+                fetch_any<VOXEL, TEX8>(V, tx[u], ty[u], tz[u], C[u]);
             }
             __builtin_amdgcn_sched_barrier(0);           // all 4U gathers are issued before the first is consumed
-#ifdef VV_X_NOALU
+#if defined(VV_X_NOALU) && !defined(VV_ZPAIR)
             // experiment build (tools/decompose.sh): keep the gathers, drop classification and blending
             if constexpr (VOXEL == VV_VOXEL_F32) {
 #pragma unroll
@@ -254,6 +274,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         if (lane == 0 && executed) atomicAdd(counter, executed);
         if (lane == 0 && slots) atomicAdd(counter + 1, slots);      // developer statistic: lane utilisation
         if (kLayout == LAYOUT_BRICKED && lane == 0 && executed) atomicAdd(counter + 2, 1ull);   // waves that sampled the bricked copy
+        if (kLayout == LAYOUT_ZPAIR && lane == 0 && executed) atomicAdd(counter + 3, 1ull);     // ... the z-pair copy
     }
 }
 
@@ -365,13 +386,13 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
             constexpr int PU = 4;
             for (int i0 = 0; i0 < kCacheDepth; i0 += PU) {
                 float tx_[PU], ty_[PU], tz_[PU];
-                Corners<VOXEL> C[PU];
+                typename CornerSel<VOXEL>::type C[PU];
 #pragma unroll
                 for (int u = 0; u < PU; ++u) {
                     tx_[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
                     ty_[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
                     tz_[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-                    fetch_corners<VOXEL, TEX8, kLayout>(V, tx_[u], ty_[u], tz_[u], C[u]);
+                    fetch_any<VOXEL, TEX8>(V, tx_[u], ty_[u], tz_[u], C[u]);
                     px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -437,6 +458,7 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
         for (int o = 32; o > 0; o >>= 1) executed += __shfl_down(executed, o);
         if ((threadIdx.x & 63) == 0 && executed) atomicAdd(counter, executed);
         if (kLayout == LAYOUT_BRICKED && (threadIdx.x & 63) == 0 && executed) atomicAdd(counter + 2, 1ull);
+        if (kLayout == LAYOUT_ZPAIR && (threadIdx.x & 63) == 0 && executed) atomicAdd(counter + 3, 1ull);
     }
 }
 
@@ -485,7 +507,9 @@ template <int SLICE>
 static void dispatch2(const MarchArgs &a, hipStream_t s)
 {
     if (a.V_type == VV_VOXEL_F32) { if (a.tex8) dispatch3<SLICE, VV_VOXEL_F32, true>(a, s); else dispatch3<SLICE, VV_VOXEL_F32, false>(a, s); }
+#ifndef VV_ZPAIR
     else                          { if (a.tex8) dispatch3<SLICE, VV_VOXEL_U8,  true>(a, s); else dispatch3<SLICE, VV_VOXEL_U8,  false>(a, s); }
+#endif
 }
 
 static void launch_rad_impl(const MarchArgs &a, hipStream_t s)
@@ -506,7 +530,9 @@ static void launch_raymarch_impl(const MarchArgs &a, hipStream_t s)
 
 } // namespace VV_BIG_NS
 
-#if defined(VV_BRICKED)
+#if defined(VV_ZPAIR)
+void launch_raymarch_zpair(const MarchArgs &a, hipStream_t s) { zpair::launch_raymarch_impl(a, s); }
+#elif defined(VV_BRICKED)
 void launch_raymarch_bricked(const MarchArgs &a, hipStream_t s) { brick::launch_raymarch_impl(a, s); }
 #elif defined(VV_BIG_VOLUME)
 void launch_raymarch_big(const MarchArgs &a, hipStream_t s) { big::launch_raymarch_impl(a, s); }
