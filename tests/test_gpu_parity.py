@@ -448,11 +448,10 @@ def test_bricked_copy_is_bit_identical(ctx, seed, monkeypatch):
 
 @pytest.mark.parametrize("seed", range(1, 48, 3))
 def test_zpair_copy_is_bit_identical(ctx, seed, monkeypatch):
-    """The z-pair copy of an f32 volume (two 16-byte gathers per sample; default for unshaded views
-    along the memory axis on volumes up to 512 MiB) forced on the sweep's cases, Phong included."""
+    """The z-pair copy of the volume (two gathers per sample; default for unshaded views along the
+    memory axis) forced on the sweep's cases: any view, both voxel types, Phong included."""
     monkeypatch.setenv("VV_ZPAIR", "1")
     vol, tf, W, H, cam, sp, phong, o = _random_case(seed)
-    vol = vol if vol.dtype == np.float32 else vol.astype(np.float32) / np.float32(255)
     ctx.load_volume(vol, tf)
     opts = vv.make_options(**o)
     got = ctx.render(W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
@@ -463,17 +462,20 @@ def test_zpair_copy_is_bit_identical(ctx, seed, monkeypatch):
     assert n_got == n and (ran or n == 0)
 
 
-def test_zpair_default_policy_and_edges(ctx):
-    """Default policy: an aligned, unshaded view of an f32 volume samples the z-pair copy; edge sizes."""
+def test_zpair_default_policy_and_edges(ctx, monkeypatch):
+    """Default policy: an aligned, unshaded view samples the z-pair copy (both voxel types); edge sizes."""
+    monkeypatch.delenv("VV_ZPAIR", raising=False)
     tf = vv.transfer_preset(vv.TF_ENGINE)
     rng = np.random.default_rng(9)
-    for dims in ((1, 1, 1), (2, 1, 3), (5, 4, 3), (17, 16, 15), (33, 9, 2)):
-        vol = (rng.integers(0, 256, size=dims[::-1], dtype=np.uint8).astype(np.float32) / np.float32(255))
+    for k, dims in enumerate(((1, 1, 1), (2, 1, 3), (5, 4, 3), (17, 16, 15), (33, 9, 2), (6, 7, 8))):
+        vol = rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)
+        if k % 2 == 0:
+            vol = vol.astype(np.float32) / np.float32(255)
         ctx.load_volume(vol, tf)
         opts = vv.make_options(step=1 / 40, count_samples=True)
         got = ctx.render(61, 47, vv.Camera(), options=opts)
         n_got = ctx.last_sample_count()
-        assert ctx.debug_counters()[3] > 0, "aligned f32 view did not take the z-pair path"
+        assert ctx.debug_counters()[3] > 0, "aligned view did not take the z-pair path"
         want, n = O.render(vol, tf, 61, 47, vv.Camera(), options=opts)
         assert_frames_close(got, want, f"zpair default {dims}")
         assert n_got == n

@@ -506,23 +506,26 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         if (!getenv("VV_LDS_RESERVE")) A.lds_reserve = beyond_caches ? 76000 : 49000;
     }
     // z-pair copy (speed only): along the memory axis the four corners (x..x+1, z..z+1) of a row come
-    // from one 16-byte gather, so a sample costs 2 gathers instead of 4.  f32 volumes, 2x the volume in
-    // HBM.  Measured on MI355X: -7 % on C1/C2, -10 % on 256^3 at C3's frame, -3 % on 512^3, but +6 % on
-    // 768^3 and +20 % on 1024^3 (rays of different z phase stop sharing slices in L2) and nothing on the
-    // Phong path: used for unshaded frames of volumes up to 512 MiB.  VV_ZPAIR=0/1 overrides.
-    bool use_zpair = !use_bricks && c->vtype == VV_VOXEL_F32 && A.strips.tile_log2w == 5 && !shading->phongShading &&
-                     c->vol_bytes <= (512ull << 20);
-    if (const char *e = getenv("VV_ZPAIR")) use_zpair = atoi(e) != 0 && !use_bricks && c->vtype == VV_VOXEL_F32;
+    // from one gather (16 bytes for f32, 4 for u8), so a sample costs 2 gathers instead of 4 (f32) or 8
+    // aligned dwords (u8).  2x the volume in HBM.  Measured on MI355X, unshaded frames:
+    //   f32: -7 % on C1/C2, -10 % on 256^3 at C3's frame, -3 % on 512^3, but +6 % on 768^3 and +20 % on
+    //        1024^3 (rays of different z phase stop sharing slices in L2): used up to 512 MiB;
+    //   u8 : -8 % (256^3), -12 % (512^3), -4 % (1024^3): used whenever the copy stays below 4 GiB;
+    //   Phong path: 0...-3 %: not used.                                  VV_ZPAIR=0/1 overrides.
+    bool use_zpair = !use_bricks && A.strips.tile_log2w == 5 && !shading->phongShading &&
+                     (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20));
+    if (const char *e = getenv("VV_ZPAIR")) use_zpair = atoi(e) != 0 && !use_bricks;
     if (use_zpair && !c->zpair_valid) {
         uint32_t rb = 0, sb = 0;
-        const size_t zb = zpair_copy_bytes(c->nx, c->ny, c->nz, &rb, &sb);
+        const size_t zb = zpair_copy_bytes(c->vtype, c->nx, c->ny, c->nz, &rb, &sb);
         size_t free_b = 0, total_b = 0;
         if ((size_t)(c->ny + 1) * ((size_t)c->nx + 1) * 8 >= (1ull << 32) || ((size_t)c->nx + 1) * 8 >= (1u << 24) ||
+            (c->vtype == VV_VOXEL_U8 && zb >= (1ull << 32)) ||                    // u8 sampler: 32-bit offsets
             hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < zb + (512ull << 20) ||
             hipMalloc(&c->d_zpair, zb + 32) != hipSuccess) {
             (void)hipGetLastError(); c->d_zpair = nullptr; use_zpair = false;
         } else {
-            launch_build_zpair((const float *)c->d_vol, (float *)c->d_zpair, c->nx, c->ny, c->nz, st);
+            launch_build_zpair(c->vtype, c->d_vol, c->d_zpair, c->nx, c->ny, c->nz, st);
             HIPCHK(c, hipMemsetAsync((char *)c->d_zpair + zb, 0, 32, st));
             HIPCHK(c, hipStreamSynchronize(st));
             c->zp_row = rb; c->zp_slab = sb; c->zpair_valid = true;

@@ -264,33 +264,43 @@ void launch_build_bricks(int vtype, const void *linear, void *bricks, int nx, in
 // ---------------------------------------------------------------------------
 // z-pair copy of an f32 volume (VolumeView::zpair, vv_device.h)
 // ---------------------------------------------------------------------------
-size_t zpair_copy_bytes(int nx, int ny, int nz, uint32_t *row_bytes, uint32_t *slab_bytes)
+size_t zpair_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *row_bytes, uint32_t *slab_bytes)
 {
-    const size_t row = ((size_t)nx + 1) * 8, slab = ((size_t)ny + 1) * row;
+    const size_t rec = vtype == VV_VOXEL_F32 ? 8 : 2;
+    const size_t row = (((size_t)nx + 1) * rec + 3) & ~(size_t)3, slab = ((size_t)ny + 1) * row;
     if (row_bytes) *row_bytes = (uint32_t)row;
     if (slab_bytes) *slab_bytes = (uint32_t)slab;
     return slab * (size_t)nz;
 }
 
-__global__ __launch_bounds__(256) void zpair_kernel(const float *__restrict__ in, float2 *__restrict__ out,
-                                                    int nx, int ny, int nz, size_t total)
+// one thread per record; rows of `row_recs` records (u8 rows may end in one unused record of padding)
+template <typename T, typename T2>
+__global__ __launch_bounds__(256) void zpair_kernel(const T *__restrict__ in, T2 *__restrict__ out,
+                                                    int nx, int ny, int nz, size_t row_recs, size_t total)
 {
-    const size_t rx = (size_t)nx + 1, ry = (size_t)ny + 1;
+    const size_t ry = (size_t)ny + 1;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const int x = min((int)(t % rx), nx - 1);
-        const size_t row = t / rx;
+        const int x = min((int)(t % row_recs), nx - 1);
+        const size_t row = t / row_recs;
         const int y = min((int)(row % ry), ny - 1), z = (int)(row / ry);
         const size_t i0 = ((size_t)z * ny + y) * nx + x, i1 = ((size_t)min(z + 1, nz - 1) * ny + y) * nx + x;
-        out[t] = make_float2(in[i0], in[i1]);
+        T2 r; r.x = in[i0]; r.y = in[i1];
+        out[t] = r;
     }
 }
 
-void launch_build_zpair(const float *linear, float *zpair, int nx, int ny, int nz, hipStream_t s)
+void launch_build_zpair(int vtype, const void *linear, void *zpair, int nx, int ny, int nz, hipStream_t s)
 {
-    const size_t total = ((size_t)nx + 1) * ((size_t)ny + 1) * (size_t)nz;
+    uint32_t rb = 0, sb = 0;
+    zpair_copy_bytes(vtype, nx, ny, nz, &rb, &sb);
+    const size_t row_recs = rb / (vtype == VV_VOXEL_F32 ? 8 : 2);
+    const size_t total = row_recs * ((size_t)ny + 1) * (size_t)nz;
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL(zpair_kernel, dim3((unsigned)blocks), dim3(256), 0, s, linear, (float2 *)zpair, nx, ny, nz, total);
+    if (vtype == VV_VOXEL_F32)
+        hipLaunchKernelGGL((zpair_kernel<float, float2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, (float2 *)zpair, nx, ny, nz, row_recs, total);
+    else
+        hipLaunchKernelGGL((zpair_kernel<uint8_t, uchar2>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, (uchar2 *)zpair, nx, ny, nz, row_recs, total);
 }
 
 // ---------------------------------------------------------------------------

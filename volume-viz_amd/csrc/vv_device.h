@@ -47,14 +47,14 @@ struct VolumeView {
     const void *bricks;
     uint32_t b_sy;          // bytes per row of bricks   (nbx * brick bytes)
     uint32_t b_sz64;        // bytes per layer of bricks (nby * b_sy) in 64-byte units
-    // Optional z-pair copy of an f32 volume for views along the memory axis (built on first use):
-    // record (x, y, z) = { v(x,y,z), v(x,y,z+1) } (8 bytes), x fastest, rows of nx+1 records, slabs of
+    // Optional z-pair copy for views along the memory axis (built on first use):
+    // record (x, y, z) = { v(x,y,z), v(x,y,z+1) } (8 bytes for f32, 2 bytes for u8), x fastest, rows of nx+1 records, slabs of
     // ny+1 rows, nz slabs; indices beyond the volume clamp.  The two x-neighbouring records of a row
     // are the four corners (x..x+1, y, z..z+1) of a sample: one 16-byte gather per row instead of
     // two 8-byte gathers, i.e. 2 gathers per sample instead of 4 (a wave-wide gather costs the same
     // 16 cycles for 8 and for 16 bytes per lane).  2x the volume in HBM.
     const void *zpair;
-    uint32_t zp_row_bytes;  // (nx+1) * 8
+    uint32_t zp_row_bytes;  // (nx+1) records, u8 rows rounded up to 4 bytes
     uint32_t zp_slab_bytes; // (ny+1) * zp_row_bytes
 };
 template <int VOXEL> struct BrickGeom;
@@ -368,6 +368,37 @@ __device__ __forceinline__ void fetch_corners_zpair(const VolumeView &V, float p
     C.c010 = r1.x; C.c011 = r1.y; C.c110 = r1.z; C.c111 = r1.w;
 }
 
+// u8 z-pair copy: records of 2 bytes, one (2-byte aligned) dword per row = (c000, c001, c100, c101).
+// Copies up to 4 GiB: 32-bit offsets on a scalar base.
+struct CornersZ8 { float wx; uint32_t r0; float wy; uint32_t r1; float wz; };
+typedef uint32_t __attribute__((aligned(2))) uint32_a2;
+
+template <bool TEX8>
+__device__ __forceinline__ void fetch_corners_zpair(const VolumeView &V, float px, float py, float pz, CornersZ8 &C)
+{
+    uint32_t ix, iy, iz;
+    C.wx = axis_coord<TEX8>(px, (float)V.nx, (float)(V.nx - 1), ix);
+    C.wy = axis_coord<TEX8>(py, (float)V.ny, (float)(V.ny - 1), iy);
+    C.wz = axis_coord<TEX8>(pz, (float)V.nz, (float)(V.nz - 1), iz);
+    const char *b0 = (const char *)V.zpair, *b1 = b0 + V.zp_row_bytes;
+    const uint32_t off = iz * V.zp_slab_bytes + __umul24(iy, V.zp_row_bytes) + (ix << 1);
+    C.r0 = *(const uint32_a2 *)(b0 + off);
+    C.r1 = *(const uint32_a2 *)(b1 + off);
+}
+
+__device__ __forceinline__ float finish_corners(const CornersZ8 &C)
+{
+    const float c000 = (float)(C.r0 & 0xffu), c001 = (float)((C.r0 >> 8) & 0xffu), c100 = (float)((C.r0 >> 16) & 0xffu), c101 = (float)(C.r0 >> 24);
+    const float c010 = (float)(C.r1 & 0xffu), c011 = (float)((C.r1 >> 8) & 0xffu), c110 = (float)((C.r1 >> 16) & 0xffu), c111 = (float)(C.r1 >> 24);
+    const float c00 = __builtin_fmaf(C.wx, c100 - c000, c000);
+    const float c10 = __builtin_fmaf(C.wx, c110 - c010, c010);
+    const float c01 = __builtin_fmaf(C.wx, c101 - c001, c001);
+    const float c11 = __builtin_fmaf(C.wx, c111 - c011, c011);
+    const float c0 = __builtin_fmaf(C.wy, c10 - c00, c00);
+    const float c1 = __builtin_fmaf(C.wy, c11 - c01, c01);
+    return __builtin_fmaf(C.wz, c1 - c0, c0);
+}
+
 // same operations as finish_corners (x, then y, then z; fma(w, b - a, a)), two at a time
 __device__ __forceinline__ float finish_corners(const CornersZ &C)
 {
@@ -426,6 +457,7 @@ __device__ __forceinline__ bool bounds_check(float x, float y, float z)
 // f32 volumes: trunc(255 * L), saturated.
 template <int VOXEL> __device__ __forceinline__ float corner_value(const Corners<VOXEL> &C) { return finish_corners<VOXEL>(C); }
 template <int VOXEL> __device__ __forceinline__ float corner_value(const CornersZ &C) { return finish_corners(C); }
+template <int VOXEL> __device__ __forceinline__ float corner_value(const CornersZ8 &C) { return finish_corners(C); }
 
 template <int VOXEL, class CT>
 __device__ __forceinline__ uint32_t classify_index(const CT &C, float px, float py, float pz)

@@ -18,7 +18,7 @@
 // This file is compiled four times: as is (linear volume up to 4 GiB), through vv_raymarch_big.hip
 // with VV_BIG_VOLUME (linear, 64-bit slice addressing), through vv_raymarch_brick.hip with
 // VV_BRICKED (volume sampled from the bricked copy) and through vv_raymarch_zpair.hip with VV_ZPAIR
-// (f32 volume sampled from the z-pair copy), so that each path pays only for itself.
+// (volume sampled from the z-pair copy), so that each path pays only for itself.
 #if defined(VV_ZPAIR)
 #define VV_BIG_NS zpair
 constexpr int kLayout = vv::LAYOUT_ZPAIR;
@@ -40,13 +40,13 @@ namespace VV_BIG_NS {
 template <int VOXEL> struct CornerSel { using type = Corners<VOXEL>; };
 #ifdef VV_ZPAIR
 template <> struct CornerSel<VV_VOXEL_F32> { using type = CornersZ; };
+template <> struct CornerSel<VV_VOXEL_U8>  { using type = CornersZ8; };
 #endif
 template <int VOXEL, bool TEX8, class CT>
 __device__ __forceinline__ void fetch_any(const VolumeView &V, float px, float py, float pz, CT &C)
 {
 #ifdef VV_ZPAIR
-    if constexpr (VOXEL == VV_VOXEL_F32) fetch_corners_zpair<TEX8>(V, px, py, pz, C);
-    else fetch_corners<VOXEL, TEX8, LAYOUT_LINEAR>(V, px, py, pz, C);
+    fetch_corners_zpair<TEX8>(V, px, py, pz, C);
 #else
     fetch_corners<VOXEL, TEX8, kLayout>(V, px, py, pz, C);
 #endif
@@ -507,9 +507,7 @@ template <int SLICE>
 static void dispatch2(const MarchArgs &a, hipStream_t s)
 {
     if (a.V_type == VV_VOXEL_F32) { if (a.tex8) dispatch3<SLICE, VV_VOXEL_F32, true>(a, s); else dispatch3<SLICE, VV_VOXEL_F32, false>(a, s); }
-#ifndef VV_ZPAIR
     else                          { if (a.tex8) dispatch3<SLICE, VV_VOXEL_U8,  true>(a, s); else dispatch3<SLICE, VV_VOXEL_U8,  false>(a, s); }
-#endif
 }
 
 static void launch_rad_impl(const MarchArgs &a, hipStream_t s)
