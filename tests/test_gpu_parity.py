@@ -433,7 +433,7 @@ def test_staged_kernel_is_bit_identical(ctx, view, monkeypatch):
 @pytest.mark.parametrize("seed", range(0, 48, 3))
 def test_bricked_copy_is_bit_identical(ctx, seed, monkeypatch):
     """The 4x4x4-brick copy of the volume (used by default for views off the memory axis on volumes
-    of 64 MiB and more) forced on the sweep's small volumes: same frames, same sample counts."""
+    of 2 M voxels and more) forced on the sweep's small volumes: same frames, same sample counts."""
     monkeypatch.setenv("VV_BRICKED", "1")
     vol, tf, W, H, cam, sp, phong, o = _random_case(seed)
     ctx.load_volume(vol, tf)
