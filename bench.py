@@ -242,6 +242,26 @@ def main():
                      "bytes_per_sample": round(bytes_rank / max(samples, 1), 3)},
     }
 
+    # Not part of `value`: the same workload seen from a direction off the memory axis (SURVEY 8d's
+    # second camera), where vv_render samples the bricked copy of the volume.
+    if world == 1 and args.config == "c3" and args.view == "a" and not args.orbit and not os.environ.get("VV_BENCH_NO_EXTRA"):
+        cam_b = vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5)
+        ctx.render_device(W, H, cam_b, frame.data_ptr(), options=vv.make_options(count_samples=True, **base), stream=stream, phong=args.phong)
+        torch.cuda.synchronize()
+        samples_b = ctx.last_sample_count()
+        for _ in range(2):
+            ctx.render_device(W, H, cam_b, frame.data_ptr(), options=opts, stream=stream, phong=args.phong)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ctx.render_device(W, H, cam_b, frame.data_ptr(), options=opts, stream=stream, phong=args.phong)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_b = e0.elapsed_time(e1) / 10
+        out["rotated_view"] = {"camera": "orbit r=4, theta=60 deg, phi=36 deg", "ms_per_frame": round(ms_b, 4),
+                               "value": round(samples_b / ms_b / 1e3, 1), "unit": "Msamples/s",
+                               "executed_samples_per_frame": int(samples_b)}
+
     if want_cpu:
         # the CPU restatement (oracle/vvo.c, OpenMP) on this box's host cores, same workload.
         # The GPU box shares its host: 16 cores is the share of one GPU.
