@@ -53,29 +53,34 @@ __device__ __forceinline__ void fetch_any(const VolumeView &V, float px, float p
 }
 
 // ---------------------------------------------------------------------------
-// rad pre-pass: one block per slab, one thread per (clamped) footprint pixel.
+// rad pre-pass (blockMin, kernel.cu:80-97,329): one wave per slab, four (clamped) footprint
+// pixels per lane, minimum by wave shuffles -- no LDS, no block barrier.  The minimum of a set of
+// floats does not depend on the order fminf visits them in, so the value equals the reference's tree.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rad_kernel(FrameParams P, float *__restrict__ rad)
 {
-    __shared__ float red[256];
-    const int bx = blockIdx.x, by = blockIdx.y;
+    const int slab = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (slab >= P.nbx * P.nby) return;                                     // wave-uniform
+    const int bx = slab % P.nbx, by = slab / P.nbx;
     // a shard only needs the radii of the slab rows that own its pixel rows: its own bands
     // (bands are whole slab rows) and, when H == 1 (mod 14), the last slab row (pin 10)
     if (!row_owned(P, by * kSlab) && !(P.conflict_y && by == P.nby - 1)) return;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    int x = bx * kSlab + tx - 1, y = by * kSlab + ty - 1;                 // kernel.cu:294-295
-    x = max(slab_lo(bx), min(x, slab_up(bx, P.W) - 1));                   // :307-308
-    y = max(slab_lo(by), min(y, slab_up(by, P.H) - 1));
-    f3 front, back;
-    ray_endpoints(P, x, y, front, back);
-    float cl = vlen3(front.x - P.cam_pos[0], front.y - P.cam_pos[1], front.z - P.cam_pos[2]);  // :323-325
-    red[threadIdx.x] = cl;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + s]);
-        __syncthreads();
+    const int lox = slab_lo(bx), upx = slab_up(bx, P.W) - 1, loy = slab_lo(by), upy = slab_up(by, P.H) - 1;
+    float m = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = lane + 64 * q, tx = t & 15, ty = t >> 4;
+        int x = bx * kSlab + tx - 1, y = by * kSlab + ty - 1;              // kernel.cu:294-295
+        x = max(lox, min(x, upx));                                         // :307-308
+        y = max(loy, min(y, upy));
+        f3 front, back;
+        ray_endpoints(P, x, y, front, back);
+        const float cl = vlen3(front.x - P.cam_pos[0], front.y - P.cam_pos[1], front.z - P.cam_pos[2]);  // :323-325
+        m = q == 0 ? cl : fminf(m, cl);
     }
-    if (threadIdx.x == 0) rad[by * P.nbx + bx] = red[0];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+    if (lane == 0) rad[slab] = m;
 }
 
 // ---------------------------------------------------------------------------
@@ -512,8 +517,8 @@ static void dispatch2(const MarchArgs &a, hipStream_t s)
 
 static void launch_rad_impl(const MarchArgs &a, hipStream_t s)
 {
-    // one block per slab of the frame; blocks of slab rows this shard does not own exit at once
-    dim3 grid(a.P.nbx, a.P.nby);
+    // one wave per slab of the frame; waves of slab rows this shard does not own exit at once
+    dim3 grid((unsigned)((a.P.nbx * a.P.nby + 3) / 4));
     hipLaunchKernelGGL(rad_kernel, grid, dim3(256), 0, s, a.P, a.rad_out);
 }
 
