@@ -274,6 +274,22 @@ int  vv_t3d_read_header(const char *path, int header, int *nx, int *ny, int *nz)
 int  vv_t3d_read (const char *path, int header, uint8_t *dst, size_t capacity);
 int  vv_t3d_write(const char *path, int header, const uint8_t *src, int nx, int ny, int nz);
 
+/* ---- optional second layouts of the loaded volume (no reference counterpart: cudaArray hides its
+ * layout).  vv_render builds them by itself on the first frame that profits (a few ms once, and a
+ * stream synchronisation); a host that wants the first frame at full speed builds them up front.
+ *   VV_LAYOUT_BRICKED  4x4x4-voxel bricks with an x halo (1.25x an f32 volume, 2x a u8 volume): sampled
+ *                      when the screen x direction is more than ~14 degrees off the volume's x axis
+ *   VV_LAYOUT_ZPAIR    {v(z), v(z+1)} records (2x the volume): sampled by unshaded frames along the x
+ *                      axis, f32 volumes up to 512 MiB and u8 volumes up to 2 GiB
+ * Both are dropped when another volume is loaded; results never depend on which layout is sampled.
+ * Returns the bit mask of the requested layouts that are resident afterwards (a layout that does
+ * not fit in free HBM is skipped, not an error), or a negative vv_status.                     */
+enum { VV_LAYOUT_BRICKED = 1, VV_LAYOUT_ZPAIR = 2 };
+int  vv_prepare_layouts(vv_context *ctx, int which, void *stream);
+/* Device memory held by the context: out[0] linear volume, [1] bricked copy, [2] z-pair copy,
+ * [3] tables and scratch (bytes). */
+int  vv_device_bytes(const vv_context *ctx, unsigned long long out[4]);
+
 /* ---- metrics (the reference only has a clock() overlay) ---------------- */
 float              vv_last_frame_ms(const vv_context *ctx);      /* hipEvent time of the last vv_render */
 unsigned long long vv_last_sample_count(vv_context *ctx);        /* executed samples, if count_samples */

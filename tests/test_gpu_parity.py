@@ -486,6 +486,32 @@ def test_zpair_default_policy_and_edges(ctx, monkeypatch):
         assert_frames_close(got, want, f"linear phong {dims}")
 
 
+def test_prepare_layouts_and_device_bytes(ctx, monkeypatch):
+    """vv_prepare_layouts builds the copies up front, vv_device_bytes accounts for them, a reload drops them."""
+    monkeypatch.delenv("VV_BRICKED", raising=False); monkeypatch.delenv("VV_ZPAIR", raising=False)
+    tf = vv.transfer_preset(vv.TF_HEAD)
+    vol = O.noise_u8(130, 129, 131, 3).astype(np.float32) / np.float32(255)        # > 2 M voxels: bricks by policy
+    ctx.load_volume(vol, tf)
+    b = ctx.device_bytes()
+    assert b[0] == vol.nbytes and b[1] == 0 and b[2] == 0
+    assert ctx.prepare_layouts(vv.LAYOUT_BRICKED | vv.LAYOUT_ZPAIR) == 3
+    b = ctx.device_bytes()
+    nbx, nby, nbz = (130 + 3) // 4, 129 // 4 + 1, 131 // 4 + 1
+    assert b[1] == nbx * nby * nbz * 320 and b[2] == 131 * (129 + 1) * (130 + 1) * 8
+    opts = vv.make_options(step=1 / 100, count_samples=True)
+    for cam, slot in ((_cam("b"), 2), (vv.Camera(), 3)):          # off axis -> bricks, along z -> z-pair
+        got = ctx.render(96, 80, cam, options=opts)
+        assert ctx.debug_counters()[slot] > 0
+        want, n = O.render(vol, tf, 96, 80, cam, options=opts)
+        assert_frames_close(got, want, f"prepared layout {slot}")
+        assert ctx.last_sample_count() == n
+    ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
+    b = ctx.device_bytes()
+    assert b[0] == 64 and b[1] == 0 and b[2] == 0
+    with pytest.raises(vv.VolvizError):
+        ctx.prepare_layouts(8)
+
+
 def test_bricked_copy_edges_and_reload(ctx, monkeypatch):
     """Volume edges not multiples of the brick size (incl. single-voxel axes), both voxel types,
     and the copy is rebuilt when another volume is loaded."""

@@ -25,9 +25,9 @@ struct vv_context {
     // volume
     void *d_vol = nullptr; size_t vol_bytes = 0; int vtype = VV_VOXEL_U8; int nx = 0, ny = 0, nz = 0;
     // bricked copy of an f32 volume for views off the memory axis (built on first use, dropped on reload)
-    void *d_bricks = nullptr; bool bricks_valid = false; uint32_t b_sy = 0, b_sz64 = 0;
+    void *d_bricks = nullptr; bool bricks_valid = false; uint32_t b_sy = 0, b_sz64 = 0; size_t bricks_bytes = 0;
     // z-pair copy of an f32 volume for views along the memory axis (same life cycle)
-    void *d_zpair = nullptr; bool zpair_valid = false; uint32_t zp_row = 0, zp_slab = 0;
+    void *d_zpair = nullptr; bool zpair_valid = false; uint32_t zp_row = 0, zp_slab = 0; size_t zpair_bytes = 0;
     // transfer function
     float4 *d_tf = nullptr; bool tf_gray = false; bool have_tf = false;
     // scratch
@@ -58,9 +58,9 @@ static int fail(vv_context *c, int code, const std::string &msg)
 static void drop_bricks(vv_context *c)
 {
     if (c->d_bricks) (void)hipFree(c->d_bricks);
-    c->d_bricks = nullptr; c->bricks_valid = false;
+    c->d_bricks = nullptr; c->bricks_valid = false; c->bricks_bytes = 0;
     if (c->d_zpair) (void)hipFree(c->d_zpair);
-    c->d_zpair = nullptr; c->zpair_valid = false;
+    c->d_zpair = nullptr; c->zpair_valid = false; c->zpair_bytes = 0;
 }
 
 static int ensure(vv_context *c, void **p, size_t *cap, size_t need)
@@ -71,6 +71,9 @@ static int ensure(vv_context *c, void **p, size_t *cap, size_t need)
     *cap = need;
     return VV_OK;
 }
+
+static bool ensure_bricks(vv_context *c, hipStream_t st);
+static bool ensure_zpair(vv_context *c, hipStream_t st);
 
 extern "C" {
 
@@ -188,6 +191,29 @@ int vv_load_volume_device(vv_context *c, const void *dev, int vtype, int nx, int
 
 // developer statistics of the last instrumented launch (staged kernel): [0] executed samples,
 // [1] stages, [2] samples served from global memory, [3] bytes staged into LDS, [4] wave compute trips
+int vv_prepare_layouts(vv_context *c, int which, void *stream)
+{
+    if (!c) return fail(nullptr, VV_ERR_INVALID, "vv_prepare_layouts: NULL context");
+    if (!c->d_vol) return fail(c, VV_ERR_NO_VOLUME, "vv_prepare_layouts: no volume loaded");
+    if (which & ~(VV_LAYOUT_BRICKED | VV_LAYOUT_ZPAIR)) return fail(c, VV_ERR_INVALID, "vv_prepare_layouts: unknown layout bit");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    int built = 0;
+    if ((which & VV_LAYOUT_BRICKED) && ensure_bricks(c, st)) built |= VV_LAYOUT_BRICKED;
+    if ((which & VV_LAYOUT_ZPAIR) && ensure_zpair(c, st)) built |= VV_LAYOUT_ZPAIR;
+    return built;
+}
+
+int vv_device_bytes(const vv_context *c, unsigned long long out[4])
+{
+    if (!c || !out) return VV_ERR_INVALID;
+    out[0] = c->d_vol ? c->vol_bytes : 0;
+    out[1] = c->bricks_valid ? c->bricks_bytes : 0;
+    out[2] = c->zpair_valid ? c->zpair_bytes : 0;
+    out[3] = c->rad_cap + c->frame_cap + c->img_cap + c->slice_cap + 4096 + 8 * sizeof(unsigned long long);
+    return VV_OK;
+}
+
 int vv_debug_counters(vv_context *c, unsigned long long out[8])
 {
     if (!c || !out || !c->counter_valid) return VV_ERR_INVALID;
@@ -309,6 +335,51 @@ int vv_volume_dims(const vv_context *c, int dims[3], int *vtype)
     if (dims) { dims[0] = c->nx; dims[1] = c->ny; dims[2] = c->nz; }
     if (vtype) *vtype = c->vtype;
     return VV_OK;
+}
+
+// Builds the bricked / z-pair copy of the loaded volume if it is missing and HBM has room.
+// Returns true when the copy is usable afterwards.  
+static bool ensure_bricks(vv_context *c, hipStream_t st)
+{
+    if (c->bricks_valid) return true;
+    uint32_t sy = 0, sz64 = 0;
+    const size_t bb = brick_copy_bytes(c->vtype, c->nx, c->ny, c->nz, &sy, &sz64);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bb + (512ull << 20) || sz64 >= (1u << 24) ||
+        hipMalloc(&c->d_bricks, bb + 16) != hipSuccess) {
+        (void)hipGetLastError(); c->d_bricks = nullptr;
+        return false;                                                     // no room: linear path
+    }
+    launch_build_bricks(c->vtype, c->d_vol, c->d_bricks, c->nx, c->ny, c->nz, st);
+    if (hipMemsetAsync((char *)c->d_bricks + bb, 0, 16, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {                         // later frames may come on another stream
+        (void)hipGetLastError(); (void)hipFree(c->d_bricks); c->d_bricks = nullptr;
+        return false;
+    }
+    c->b_sy = sy; c->b_sz64 = sz64; c->bricks_bytes = bb; c->bricks_valid = true;
+    return true;
+}
+
+static bool ensure_zpair(vv_context *c, hipStream_t st)
+{
+    if (c->zpair_valid) return true;
+    uint32_t rb = 0, sb = 0;
+    const size_t zb = zpair_copy_bytes(c->vtype, c->nx, c->ny, c->nz, &rb, &sb);
+    size_t free_b = 0, total_b = 0;
+    if ((size_t)(c->ny + 1) * ((size_t)c->nx + 1) * 8 >= (1ull << 32) || ((size_t)c->nx + 1) * 8 >= (1u << 24) ||
+        (c->vtype == VV_VOXEL_U8 && zb >= (1ull << 32)) ||                // u8 sampler: 32-bit offsets
+        hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < zb + (512ull << 20) ||
+        hipMalloc(&c->d_zpair, zb + 32) != hipSuccess) {
+        (void)hipGetLastError(); c->d_zpair = nullptr;
+        return false;
+    }
+    launch_build_zpair(c->vtype, c->d_vol, c->d_zpair, c->nx, c->ny, c->nz, st);
+    if (hipMemsetAsync((char *)c->d_zpair + zb, 0, 32, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipFree(c->d_zpair); c->d_zpair = nullptr;
+        return false;
+    }
+    c->zp_row = rb; c->zp_slab = sb; c->zpair_bytes = zb; c->zpair_valid = true;
+    return true;
 }
 
 static VolumeView view_of(const vv_context *c)
@@ -487,20 +558,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // only volumes far below the frame's sampling density lose (64^3 at 1080p, step 1/512: +10 %).
     bool use_bricks = A.strips.tile_log2w == 3 && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
     if (const char *e = getenv("VV_BRICKED")) use_bricks = atoi(e) != 0;
-    if (use_bricks && !c->bricks_valid) {
-        uint32_t sy = 0, sz64 = 0;
-        const size_t bb = brick_copy_bytes(c->vtype, c->nx, c->ny, c->nz, &sy, &sz64);
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bb + (512ull << 20) || sz64 >= (1u << 24) ||
-            hipMalloc(&c->d_bricks, bb + 16) != hipSuccess) {
-            (void)hipGetLastError(); c->d_bricks = nullptr; use_bricks = false;      // no room: linear path
-        } else {
-            launch_build_bricks(c->vtype, c->d_vol, c->d_bricks, c->nx, c->ny, c->nz, st);
-            HIPCHK(c, hipMemsetAsync((char *)c->d_bricks + bb, 0, 16, st));
-            HIPCHK(c, hipStreamSynchronize(st));      // later frames may come on another stream
-            c->b_sy = sy; c->b_sz64 = sz64; c->bricks_valid = true;
-        }
-    }
+    if (use_bricks) use_bricks = ensure_bricks(c, st);
     if (use_bricks) {
         A.V.bricks = c->d_bricks; A.V.b_sy = c->b_sy; A.V.b_sz64 = c->b_sz64;
         // measured (C3 rotated, 1024^3): 2 blocks per CU and 2 samples per trip: 3.64 -> 1.60 ms
@@ -517,22 +575,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     bool use_zpair = !use_bricks && A.strips.tile_log2w == 5 && !shading->phongShading &&
                      (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20));
     if (const char *e = getenv("VV_ZPAIR")) use_zpair = atoi(e) != 0 && !use_bricks;
-    if (use_zpair && !c->zpair_valid) {
-        uint32_t rb = 0, sb = 0;
-        const size_t zb = zpair_copy_bytes(c->vtype, c->nx, c->ny, c->nz, &rb, &sb);
-        size_t free_b = 0, total_b = 0;
-        if ((size_t)(c->ny + 1) * ((size_t)c->nx + 1) * 8 >= (1ull << 32) || ((size_t)c->nx + 1) * 8 >= (1u << 24) ||
-            (c->vtype == VV_VOXEL_U8 && zb >= (1ull << 32)) ||                    // u8 sampler: 32-bit offsets
-            hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < zb + (512ull << 20) ||
-            hipMalloc(&c->d_zpair, zb + 32) != hipSuccess) {
-            (void)hipGetLastError(); c->d_zpair = nullptr; use_zpair = false;
-        } else {
-            launch_build_zpair(c->vtype, c->d_vol, c->d_zpair, c->nx, c->ny, c->nz, st);
-            HIPCHK(c, hipMemsetAsync((char *)c->d_zpair + zb, 0, 32, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            c->zp_row = rb; c->zp_slab = sb; c->zpair_valid = true;
-        }
-    }
+    if (use_zpair) use_zpair = ensure_zpair(c, st);
     if (use_zpair) { A.V.zpair = c->d_zpair; A.V.zp_row_bytes = c->zp_row; A.V.zp_slab_bytes = c->zp_slab; }
     A.lds_reserve_phong = beyond_caches ? 40000 : 20000;    // 3 / 4 blocks per CU (measured: 3.02 -> 2.68 ms on C3 + Phong)
     if (const char *e = getenv("VV_LDS_RESERVE_PHONG")) { int t = atoi(e); if (t >= 0 && t <= 146 * 1024) A.lds_reserve_phong = t; }

@@ -25,6 +25,7 @@ SLICE_NONE, SLICE_PLANE, SLICE_PLANE_CUT = -1, 0, 1
 # params.h:46
 HORIZONTAL, SAGITTAL, CORONAL, FREE_FORM = 0, 1, 2, 4
 VOXEL_U8, VOXEL_F32 = 0, 1
+LAYOUT_BRICKED, LAYOUT_ZPAIR = 1, 2
 FILTER_TEX8, FILTER_EXACT = 0, 1
 ERT_REFERENCE, ERT_TRUE = 0, 1
 RAYS_IMAGES, RAYS_ANALYTIC = 0, 1
@@ -67,6 +68,7 @@ EXPORTS = [
     "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid", "vv_debug_counters",
     "vv_first_pass", "vv_cut_plane_canonical", "vv_cut_plane_to_slice_params", "vv_slice_to_bgra",
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
+    "vv_prepare_layouts", "vv_device_bytes",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
 ]
 
@@ -121,6 +123,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_cut_plane_from_drag.argtypes = [vp, vp, vp, f, vp, vp, vp, vp, vp, vp]
     lib.vv_cut_plane_drag.argtypes = [vp, vp, vp, i, i, i, i]
     lib.vv_debug_counters.argtypes = [vp, vp]
+    lib.vv_prepare_layouts.argtypes = [vp, i, vp]
+    lib.vv_device_bytes.argtypes = [vp, vp]
     lib.vv_volume_dims.argtypes = [vp, C.POINTER(i * 3), C.POINTER(i)]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -333,6 +337,19 @@ class Context:
 
     def last_sample_count(self) -> int:
         return int(self.lib.vv_last_sample_count(self.h))
+
+    def prepare_layouts(self, which: int = 3, stream=None) -> int:
+        """vv_prepare_layouts: build the bricked (1) / z-pair (2) copies now; returns the resident mask."""
+        rc = self.lib.vv_prepare_layouts(self.h, which, stream)
+        if rc < 0:
+            self._chk(rc)
+        return rc
+
+    def device_bytes(self):
+        """vv_device_bytes: [linear volume, bricked copy, z-pair copy, tables + scratch]."""
+        out = np.zeros(4, np.uint64)
+        self._chk(self.lib.vv_device_bytes(self.h, out.ctypes.data))
+        return [int(v) for v in out]
 
     # invoke_slice_kernel (kernel.cu:506-519) / slicekernel.cu legacy
     def slice(self, height: int, width: int, dx=0.0, dy=0.0, dz=0.0, orientation=SAGITTAL,
