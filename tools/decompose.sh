@@ -10,7 +10,7 @@ cd "$(dirname "$0")/../volume-viz_amd"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-value"
 for X in NOLOAD NOALU; do
   mkdir -p build_x
-  for f in vv_raymarch vv_raymarch_big vv_raymarch_wstaged vv_aux; do /opt/rocm/bin/hipcc $FLAGS -DVV_X_$X -c csrc/$f.hip -o build_x/$f.o & done
+  for f in vv_raymarch vv_raymarch_big vv_raymarch_brick vv_raymarch_zpair vv_raymarch_wstaged vv_aux; do /opt/rocm/bin/hipcc $FLAGS -DVV_X_$X -c csrc/$f.hip -o build_x/$f.o & done
   /opt/rocm/bin/hipcc $FLAGS -DVV_X_$X -x hip -c csrc/vv_api.cpp -o build_x/vv_api.o &
   g++ -O2 -std=c++17 -fPIC -c csrc/vv_host.cpp -o build_x/vv_host.o &
   wait

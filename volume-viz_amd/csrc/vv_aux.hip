@@ -227,15 +227,16 @@ void launch_promote_u8_f32(const uint8_t *in, float *out, size_t n, hipStream_t 
 size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_t *sz64)
 {
     const size_t brick = vtype == VV_VOXEL_F32 ? BrickGeom<VV_VOXEL_F32>::brick : BrickGeom<VV_VOXEL_U8>::brick;
-    const size_t nbx = ((size_t)nx + 3) / 4, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
+    const size_t bxv = vtype == VV_VOXEL_F32 ? BrickGeom<VV_VOXEL_F32>::bx : BrickGeom<VV_VOXEL_U8>::bx;
+    const size_t nbx = ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
     const size_t row = nbx * brick, layer = nby * row;            // brick sizes are multiples of 64
     if (sy) *sy = (uint32_t)row;
     if (sz64) *sz64 = (uint32_t)(layer >> 6);
     return nbz * layer;
 }
 
-// one thread per stored element: E elements per brick row (5 floats / 8 bytes), 16 rows per brick
-template <typename T, int E>
+// one thread per stored element: E elements per brick row (BX voxels + halo [+ padding]), 16 rows per brick
+template <typename T, int E, int BX>
 __global__ __launch_bounds__(256) void brick_kernel(const T *__restrict__ in, T *__restrict__ out,
                                                     int nx, int ny, int nz, size_t nbx, size_t nby, size_t total)
 {
@@ -243,22 +244,24 @@ __global__ __launch_bounds__(256) void brick_kernel(const T *__restrict__ in, T 
         const int e = (int)(t % E), r = (int)((t / E) % 16);
         const size_t b = t / (E * 16);
         const size_t bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
-        const int x = min((int)bx * 4 + e, nx - 1), y = min((int)by * 4 + (r & 3), ny - 1), z = min((int)bz * 4 + (r >> 2), nz - 1);
-        out[t] = e <= 4 ? in[((size_t)z * ny + y) * nx + x] : T(0);
+        const int x = min((int)bx * BX + e, nx - 1), y = min((int)by * 4 + (r & 3), ny - 1), z = min((int)bz * 4 + (r >> 2), nz - 1);
+        out[t] = e <= BX ? in[((size_t)z * ny + y) * nx + x] : T(0);
     }
 }
 
 void launch_build_bricks(int vtype, const void *linear, void *bricks, int nx, int ny, int nz, hipStream_t s)
 {
-    const size_t nbx = ((size_t)nx + 3) / 4, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
-    const size_t per_brick = vtype == VV_VOXEL_F32 ? 80 : 128;
+    constexpr int FBX = BrickGeom<VV_VOXEL_F32>::bx;
+    const size_t bxv = vtype == VV_VOXEL_F32 ? FBX : 4;
+    const size_t nbx = ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
+    const size_t per_brick = vtype == VV_VOXEL_F32 ? 16 * (FBX + 1) : 128;
     const size_t total = nbx * nby * nbz * per_brick;
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (vtype == VV_VOXEL_F32)
-        hipLaunchKernelGGL((brick_kernel<float, 5>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, (float *)bricks, nx, ny, nz, nbx, nby, total);
+        hipLaunchKernelGGL((brick_kernel<float, FBX + 1, FBX>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, (float *)bricks, nx, ny, nz, nbx, nby, total);
     else
-        hipLaunchKernelGGL((brick_kernel<uint8_t, 8>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, (uint8_t *)bricks, nx, ny, nz, nbx, nby, total);
+        hipLaunchKernelGGL((brick_kernel<uint8_t, 8, 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, (uint8_t *)bricks, nx, ny, nz, nbx, nby, total);
 }
 
 // ---------------------------------------------------------------------------

@@ -58,8 +58,11 @@ struct VolumeView {
     uint32_t zp_slab_bytes; // (ny+1) * zp_row_bytes
 };
 template <int VOXEL> struct BrickGeom;
-template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t brick = 320, row = 20; };
-template <> struct BrickGeom<VV_VOXEL_U8>  { static constexpr uint32_t brick = 128, row = 8; };
+#ifndef VV_BRICK_XLOG2
+#define VV_BRICK_XLOG2 2          // f32 bricks are (1 << VV_BRICK_XLOG2) voxels long in x (experiment knob)
+#endif
+template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t xlog2 = VV_BRICK_XLOG2, bx = 1u << xlog2, row = (bx + 1) * 4, brick = 16 * row; };
+template <> struct BrickGeom<VV_VOXEL_U8>  { static constexpr uint32_t xlog2 = 2, bx = 4, row = 8, brick = 128; };
 enum { LAYOUT_LINEAR = 0, LAYOUT_LINEAR_BIG = 1, LAYOUT_BRICKED = 2, LAYOUT_ZPAIR = 3 };
 
 // Everything a frame needs that is uniform over the launch.
@@ -330,8 +333,14 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
         const char *L0 = (const char *)V.bricks + ((uint64_t)m0 << 6);
         const char *L1 = (const char *)V.bricks + ((uint64_t)m1 << 6);
         if constexpr (VOXEL == VV_VOXEL_F32) {
-            const uint32_t ox = __umul24(ix >> 2, G::brick) + ((ix & 3u) << 2);
+            const uint32_t ox = __umul24(ix >> G::xlog2, G::brick) + ((ix & (G::bx - 1u)) << 2);
             const uint32_t o0 = ox + oy0, o1 = ox + oy1;
+#ifdef VV_X_NOLOAD
+            {   // experiment build (tools/decompose.sh): keep the address arithmetic, drop the gathers
+                const uint64_t h = (uint64_t)(L0 + (o0 + zi0)) ^ (uint64_t)(L0 + (o1 + zi0)) ^ (uint64_t)(L1 + (o0 + zi1)) ^ (uint64_t)(L1 + (o1 + zi1));
+                float f = __uint_as_float(((uint32_t)h & 0xffffu) | 0x3a000000u); C.a = {f, f}; C.b = C.a; C.c = C.a; C.d = C.a; return;
+            }
+#endif
             C.a = *(const float2u *)(L0 + (o0 + zi0)); C.b = *(const float2u *)(L0 + (o1 + zi0));
             C.c = *(const float2u *)(L1 + (o0 + zi1)); C.d = *(const float2u *)(L1 + (o1 + zi1));
         } else {
