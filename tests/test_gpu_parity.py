@@ -663,6 +663,12 @@ def test_volume_above_4gib(ctx, monkeypatch):
         got_band = np.zeros_like(full)
         ctx.render(W, H, cam, options=vv.make_options(step=1 / 320, slab_rows=band, count_samples=True), out=got_band)
         assert ctx.last_sample_count() == n_band and n_band < n_full
+    # the slice sampler on the same volume (its kernels pick 64-bit addressing at run time)
+    for orient, d in ((vv.SAGITTAL, (0.0, 0.0, 0.93)), (vv.CORONAL, (0.97, 0.0, 0.0)), (vv.HORIZONTAL, (0.0, 0.99, 0.0))):
+        got = ctx.slice(96, 96, *d, orientation=orient, fill=-1.0)
+        assert np.array_equal(got, O.slice(host, 96, 96, *d, orientation=orient, fill=-1.0)), orient
+    m = O.slice_matrix(0.3, 0.3, 0.3, 0.4, -0.7, 1.1)
+    assert np.array_equal(ctx.slice_advanced(80, 80, m, fill=-1.0), O.slice_advanced(host, 80, 80, m, fill=-1.0))
     # free the 8.4 GB volume for the tests that follow
     ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
 
