@@ -78,8 +78,11 @@ class FrameGatherer:
         self.frames = [torch.zeros((hp, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
         nb = hp // BAND_PX // world
         self.mine = [torch.empty((nb, BAND_PX, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
-        self.recv = [[torch.empty_like(self.mine[0]) for _ in range(world)] if (rank == 0 and world > 1) else None
-                     for _ in range(depth)]
+        # rank 0 receives into one tensor per buffer, [world, nb, BAND_PX, W, 4], so that the bands of
+        # all ranks go back to their rows with a single strided copy
+        self.recv_all = [torch.empty((world, nb, BAND_PX, width, 4), dtype=torch.uint8, device=device)
+                         if (rank == 0 and world > 1) else None for _ in range(depth)]
+        self.recv = [[ra[r] for r in range(world)] if ra is not None else None for ra in self.recv_all]
         self.work = [None] * depth
 
     def submit(self, b: int) -> None:
@@ -104,9 +107,8 @@ class FrameGatherer:
             return None
         f = self.frames[b]
         hp, w, c = f.shape
-        out = f.view(hp // BAND_PX, BAND_PX, w, c)
-        for r in range(1, self.world):
-            out[r::self.world] = self.recv[b][r]
+        # band k*world + r of the frame is band k of rank r (rank 0's own bands come back unchanged)
+        f.view(hp // BAND_PX // self.world, self.world, BAND_PX, w, c).copy_(self.recv_all[b].transpose(0, 1))
         return f
 
     def drain(self):
