@@ -35,6 +35,7 @@ struct vv_context {
     uint8_t *d_frame = nullptr; size_t frame_cap = 0;
     uint8_t *d_img = nullptr; size_t img_cap = 0;
     float *d_slice = nullptr; size_t slice_cap = 0;
+    float *d_gen = nullptr; size_t gen_cap = 0;       // per-axis tables of the ellipsoid generator
     unsigned long long *d_counter = nullptr;
     bool counter_valid = false;
     // streamed upload
@@ -115,6 +116,7 @@ int vv_shutdown(vv_context *c)
     if (c->d_frame) hipFree(c->d_frame);
     if (c->d_img) hipFree(c->d_img);
     if (c->d_slice) hipFree(c->d_slice);
+    if (c->d_gen) hipFree(c->d_gen);
     if (c->d_counter) hipFree(c->d_counter);
     for (int i = 0; i < 2; ++i) {
         if (c->pin[i]) hipHostFree(c->pin[i]);
@@ -769,7 +771,11 @@ static int generate_impl(vv_context *c, uint8_t *out, int out_on_device, int nx,
         if (in_place && hipMemcpyAsync(d, out, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { hipFree(tmp); return fail(c, VV_ERR_DEVICE, "vv_draw_ellipsoid: upload failed"); }
     }
     if (((uintptr_t)d & 15) != 0) { if (tmp) hipFree(tmp); return fail(c, VV_ERR_INVALID, "vv_generate_ellipsoids: device buffer must be 16-byte aligned"); }
-    launch_generate_ellipsoids(d, nx, ny, nz, n, centers, axes, colors, in_place, st);
+    {
+        int rc = ensure(c, (void **)&c->d_gen, &c->gen_cap, generate_scratch_floats(nx, ny, nz, n) * sizeof(float));
+        if (rc) { if (tmp) hipFree(tmp); return rc; }
+    }
+    launch_generate_ellipsoids(d, nx, ny, nz, n, centers, axes, colors, in_place, c->d_gen, st);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && !out_on_device) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && (!out_on_device || !stream)) e = hipStreamSynchronize(st);

@@ -48,9 +48,10 @@ struct SliceArgs {
 void launch_slice(const SliceArgs &a, hipStream_t s);
 void launch_first_pass(const FrameParams &P, uint32_t *front, uint32_t *back, hipStream_t s);
 
+size_t generate_scratch_floats(int nx, int ny, int nz, int n);
 void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
                                 const float *centers, const float *axes, const uint8_t *colors,
-                                int in_place, hipStream_t s);
+                                int in_place, float *scratch /* generate_scratch_floats() device floats */, hipStream_t s);
 void launch_promote_u8_f32(const uint8_t *in, float *out, size_t n, hipStream_t s);
 void launch_noise_u8(uint8_t *out, int nx, int ny, int nz, uint32_t seed, hipStream_t s);
 
