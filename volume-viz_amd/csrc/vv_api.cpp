@@ -540,16 +540,19 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     }
     if (const char *e = getenv("VV_TILE_LOG2W")) { int t = atoi(e); if (t >= 3 && t <= 5) A.strips.tile_log2w = t; }
     // Occupancy cap + gathers in flight (speed only; measured on MI355X):
-    //   volume beyond the caches (> 1 GiB), aligned view : 2 blocks per CU, 2 samples per trip
-    //   volume beyond the caches, rotated view           : 1 block  per CU, 3 samples per trip
-    //   smaller volumes                                  : 3 blocks per CU, 2 samples per trip
+    //   volume beyond the caches (> 1 GiB), aligned view : 2 blocks per CU, 3 samples per trip
+    //   volume beyond the caches, rotated, linear layout : 1 block  per CU, 3 samples per trip
+    //   smaller volumes                                  : 3 blocks per CU, 3 (aligned) / 2 samples per trip
+    //   bricked copy (below)                             : 2 / 3 blocks per CU, 2 samples per trip
     // LDS per block = 4 KB table + reserve; 160 KB per CU.  VV_LDS_RESERVE / VV_UNROLL override.
     // XCD-aware block order: XCD k renders strips k, k+8, ... (each a full-width row of tiles), so
     // the tiles that share volume cache lines share an L2 (measured: -4 % on every workload)
     A.strips.xcd_band = 1;
     if (const char *e = getenv("VV_XCD_BAND")) { int t = atoi(e); if (t >= 0 && t <= 64) A.strips.xcd_band = t; }
     const bool beyond_caches = c->vol_bytes > (1ull << 30);
-    A.unroll = (beyond_caches && A.strips.tile_log2w == 3) ? 3 : 2;
+    // 3 samples per trip along the memory axis (A/B with repeats on MI355X: C3 -1.6 %, C2 -5.7 %, 512^3 -10 %,
+    // u8 1024^3 -6.5 %; 4 per trip is no better), 2 on the bricked copy (3 there: +3.5 %)
+    A.unroll = (A.strips.tile_log2w == 5 || beyond_caches) ? 3 : 2;
     A.lds_reserve = !beyond_caches ? 49000 : (A.strips.tile_log2w == 5 ? 76000 : 155000);
     if (const char *e = getenv("VV_UNROLL")) { int t = atoi(e); if (t == 2 || t == 3) A.unroll = t; }
     if (const char *e = getenv("VV_LDS_RESERVE")) { int t = atoi(e); if (t >= 0 && t <= 155 * 1024) A.lds_reserve = t; }
