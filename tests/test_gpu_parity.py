@@ -505,6 +505,17 @@ def test_prepare_layouts_and_device_bytes(ctx, monkeypatch):
         want, n = O.render(vol, tf, 96, 80, cam, options=opts)
         assert_frames_close(got, want, f"prepared layout {slot}")
         assert ctx.last_sample_count() == n
+    # u8, copies built lazily by the default policy; Phong off axis samples the bricks as well
+    vol8 = O.noise_u8(160, 121, 110, 5)
+    ctx.load_volume(vol8, tf)
+    for cam, phong, slot in ((_cam("c"), False, 2), (_cam("b"), True, 2), (vv.Camera(), False, 3)):
+        got = ctx.render(96, 80, cam, phong=phong, options=opts)
+        assert ctx.debug_counters()[slot] > 0
+        want, n = O.render(vol8, tf, 96, 80, cam, phong=phong, options=opts)
+        assert_frames_close(got, want, f"u8 default layout {slot} phong={phong}")
+        assert ctx.last_sample_count() == n
+    b = ctx.device_bytes()
+    assert b[1] == (160 // 4) * (121 // 4 + 1) * (110 // 4 + 1) * 128 and b[2] == 110 * (121 + 1) * ((160 + 1) * 2 + 2)
     ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
     b = ctx.device_bytes()
     assert b[0] == 64 and b[1] == 0 and b[2] == 0
