@@ -582,7 +582,10 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (const char *e = getenv("VV_ZPAIR")) use_zpair = atoi(e) != 0 && !use_bricks;
     if (use_zpair) use_zpair = ensure_zpair(c, st);
     if (use_zpair) { A.V.zpair = c->d_zpair; A.V.zp_row_bytes = c->zp_row; A.V.zp_slab_bytes = c->zp_slab; }
-    A.lds_reserve_phong = beyond_caches ? 40000 : 20000;    // 3 / 4 blocks per CU (measured: 3.02 -> 2.68 ms on C3 + Phong)
+    // Phong kernel: 14.3 KB of LDS per block + this reserve.  Measured (tools/ab_phong.sh): volumes up to
+    // 1 GiB like 5 blocks per CU (C2 0.54 -> 0.47 ms against no cap, u8 1024^3 1.88 -> 1.78), the 4 GiB
+    // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)
+    A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : (beyond_caches ? 30000 : 13000);
     if (const char *e = getenv("VV_LDS_RESERVE_PHONG")) { int t = atoi(e); if (t >= 0 && t <= 146 * 1024) A.lds_reserve_phong = t; }
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
