@@ -493,7 +493,7 @@ def test_prepare_layouts_and_device_bytes(ctx, monkeypatch):
     vol = O.noise_u8(130, 129, 131, 3).astype(np.float32) / np.float32(255)        # > 2 M voxels: bricks by policy
     ctx.load_volume(vol, tf)
     b = ctx.device_bytes()
-    assert b[0] == vol.nbytes and b[1] == 0 and b[2] == 0
+    assert b[0] == vol.nbytes + (129 + 1) * 130 * 4 + 16 and b[1] == 0 and b[2] == 0      # + one slice + one row + 16 B of padding
     assert ctx.prepare_layouts(vv.LAYOUT_BRICKED | vv.LAYOUT_ZPAIR) == 3
     b = ctx.device_bytes()
     nbx, nby, nbz = (130 + 3) // 4, 129 // 4 + 1, 131 // 4 + 1
@@ -518,9 +518,50 @@ def test_prepare_layouts_and_device_bytes(ctx, monkeypatch):
     assert b[1] == (160 // 4) * (121 // 4 + 1) * (110 // 4 + 1) * 128 and b[2] == 110 * (121 + 1) * ((160 + 1) * 2 + 2)
     ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
     b = ctx.device_bytes()
-    assert b[0] == 64 and b[1] == 0 and b[2] == 0
+    assert b[0] == 64 + 16 + 4 + 16 and b[1] == 0 and b[2] == 0
     with pytest.raises(vv.VolvizError):
         ctx.prepare_layouts(8)
+
+
+@pytest.mark.parametrize("dims,dtype", [((256, 9, 7), np.float32), ((256, 32, 5), np.float32), ((512, 3, 4), np.float32),
+                                        ((1024, 5, 6), np.uint8), ((2048, 4, 3), np.uint8)])
+def test_padded_pitch_layout(ctx, dims, dtype, monkeypatch):
+    """f32 volumes whose rows are a multiple of 1 KiB are re-pitched on the device (rows + 128 B, and one
+    more row per slice if a slice would still be a multiple of 4 KiB): every consumer of the linear layout
+    and the builders of the two copies read it through the pitches (u8 volumes take the same code, dense)."""
+    rng = np.random.default_rng(17)
+    vol = rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)
+    if dtype == np.float32:
+        vol = vol.astype(np.float32) / np.float32(255)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    nx, ny, nz = dims
+    row = nx * vol.itemsize + (128 if dtype == np.float32 else 0)         # u8 volumes stay dense
+    rows = ny + (1 if dtype == np.float32 and (ny * row) % 4096 == 0 else 0)
+    assert ctx.device_bytes()[0] == nz * rows * row + rows * row + row + 16
+    opts = vv.make_options(step=1 / 60, count_samples=True)
+    for env in ({}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}):
+        for k in ("VV_BRICKED", "VV_ZPAIR"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for cam, phong in ((vv.Camera(), False), (vv.Camera(), True), (_cam("b"), False), (_cam("c"), True)):
+            got = ctx.render(75, 59, cam, phong=phong, options=opts)
+            want, n = O.render(vol, tf, 75, 59, cam, phong=phong, options=opts)
+            assert_frames_close(got, want, f"padded {dims} {env} phong={phong}")
+            assert ctx.last_sample_count() == n
+    for orient in (vv.SAGITTAL, vv.CORONAL, vv.HORIZONTAL):
+        assert np.array_equal(ctx.slice(40, 33, 0.1, 0.2, 0.3, orientation=orient, fill=-1.0),
+                              O.slice(vol, 40, 33, 0.1, 0.2, 0.3, orientation=orient, fill=-1.0))
+    # streamed upload ends in the same padded layout
+    ctx.load_volume_streamed(((z, vol[z:z + 2]) for z in range(0, nz, 2)), vv.VOXEL_U8 if dtype == np.uint8 else vv.VOXEL_F32, nx, ny, nz, tf)
+    assert ctx.device_bytes()[0] == nz * rows * row + rows * row + row + 16
+    got = ctx.render(75, 59, _cam("c"), options=opts)
+    want, _ = O.render(vol, tf, 75, 59, _cam("c"), options=opts)
+    assert_frames_close(got, want, f"padded streamed {dims}")
+    monkeypatch.setenv("VV_PITCH_PAD", "0")
+    ctx.load_volume(vol, tf)
+    assert ctx.device_bytes()[0] == vol.nbytes + ny * nx * vol.itemsize + nx * vol.itemsize + 16
 
 
 def test_bricked_copy_edges_and_reload(ctx, monkeypatch):

@@ -24,6 +24,7 @@ struct vv_context {
     bool timed = false;
     // volume
     void *d_vol = nullptr; size_t vol_bytes = 0; int vtype = VV_VOXEL_U8; int nx = 0, ny = 0, nz = 0;
+    size_t row_pitch = 0, slice_pitch = 0, alloc_bytes = 0;   // linear layout in HBM (bytes); vol_bytes stays nx*ny*nz*voxel
     // bricked copy of an f32 volume for views off the memory axis (built on first use, dropped on reload)
     void *d_bricks = nullptr; bool bricks_valid = false; uint32_t b_sy = 0, b_sz64 = 0; size_t bricks_bytes = 0;
     // z-pair copy of an f32 volume for views along the memory axis (same life cycle)
@@ -73,6 +74,7 @@ static int ensure(vv_context *c, void **p, size_t *cap, size_t need)
     return VV_OK;
 }
 
+static int finalize_layout(vv_context *c, hipStream_t st);
 static bool ensure_bricks(vv_context *c, hipStream_t st);
 static bool ensure_zpair(vv_context *c, hipStream_t st);
 
@@ -170,8 +172,10 @@ static int install_volume(vv_context *c, const void *src, bool src_on_device, in
     HIPCHK(c, hipMemsetAsync((char *)c->d_vol + bytes, 0, pad, st));
     if (src_on_device) HIPCHK(c, hipMemcpyAsync(c->d_vol, src, bytes, hipMemcpyDeviceToDevice, st));
     else { HIPCHK(c, hipMemcpyAsync(c->d_vol, src, bytes, hipMemcpyHostToDevice, st)); }
-    if (!src_on_device || !s) HIPCHK(c, hipStreamSynchronize(st));
     c->vol_bytes = bytes; c->vtype = vtype; c->nx = nx; c->ny = ny; c->nz = nz;
+    c->row_pitch = (size_t)nx * vsz; c->slice_pitch = c->row_pitch * ny; c->alloc_bytes = bytes + pad;
+    { int rc = finalize_layout(c, st); if (rc) return rc; }
+    if (!src_on_device || !s) HIPCHK(c, hipStreamSynchronize(st));
     if (tf) return vv_set_transfer_function(c, tf);
     return VV_OK;
 }
@@ -209,7 +213,7 @@ int vv_prepare_layouts(vv_context *c, int which, void *stream)
 int vv_device_bytes(const vv_context *c, unsigned long long out[4])
 {
     if (!c || !out) return VV_ERR_INVALID;
-    out[0] = c->d_vol ? c->vol_bytes : 0;
+    out[0] = c->d_vol ? c->alloc_bytes : 0;
     out[1] = c->bricks_valid ? c->bricks_bytes : 0;
     out[2] = c->zpair_valid ? c->zpair_bytes : 0;
     out[3] = c->rad_cap + c->frame_cap + c->img_cap + c->slice_cap + 4096 + 8 * sizeof(unsigned long long);
@@ -244,6 +248,7 @@ int vv_load_volume_stream_begin(vv_context *c, int vtype, int nx, int ny, int nz
     if (!c->copy_stream) HIPCHK(c, hipStreamCreate(&c->copy_stream));
     HIPCHK(c, hipMemsetAsync((char *)c->d_vol + bytes, 0, pad, c->copy_stream));
     c->vol_bytes = bytes; c->vtype = vtype; c->nx = nx; c->ny = ny; c->nz = nz;
+    c->row_pitch = (size_t)nx * vsz; c->slice_pitch = c->row_pitch * ny; c->alloc_bytes = bytes + pad;
     c->streaming = true;
     if (tf) return vv_set_transfer_function(c, tf);
     return VV_OK;
@@ -297,6 +302,8 @@ int vv_load_volume_stream_end(vv_context *c)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     c->streaming = false;
+    { int rc = finalize_layout(c, c->copy_stream); if (rc) return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     return VV_OK;
 }
 
@@ -339,6 +346,40 @@ int vv_volume_dims(const vv_context *c, int dims[3], int *vtype)
     return VV_OK;
 }
 
+// Pitch of the linear layout.  A row pitch that is a multiple of 1 KiB (1024^3 f32: 4 KiB) puts the four
+// rows a sample gathers from (y, y+1, z, z+1) on the same cache channels: the same frame takes 9 % longer
+// on a 1024^3 volume than on 1016^3 or 1032^3 (tools/ab_size.sh).  Such volumes are re-pitched on the
+// device after the upload: rows get 128 bytes of padding and, if a slice would still be a multiple of
+// 4 KiB, one extra row.  Needs the old and the new buffer side by side for a moment; if that does not
+// fit, the dense layout stays.  Measured on C3 (A/B on one box): 1.193 -> 1.142 ms although the padded
+// 1024^3 volume is 4.4 GB and so takes the 64-bit slice addressing (+3 % by itself); nothing on the Phong
+// path; u8 volumes (1 KiB rows) gain nothing on the paths that still read the linear layout, so only f32
+// volumes are re-pitched.  VV_PITCH_PAD=0 disables.
+static int finalize_layout(vv_context *c, hipStream_t st)
+{
+    if (const char *e = getenv("VV_PITCH_PAD")) if (atoi(e) == 0) return VV_OK;
+    if (c->vtype != VV_VOXEL_F32) return VV_OK;
+    const size_t dense_row = c->row_pitch;
+    if (dense_row % 1024 != 0) return VV_OK;
+    const size_t row = dense_row + 128;
+    size_t rows = (size_t)c->ny;
+    if ((rows * row) % 4096 == 0) rows += 1;
+    const size_t slice = rows * row;
+    if (slice > 0xFFFFFFF0ull || row >= (1u << 24)) return VV_OK;
+    const size_t bytes = slice * (size_t)c->nz, pad = slice + row + 16;
+    size_t free_b = 0, total_b = 0;
+    void *nv = nullptr;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + pad + (512ull << 20) ||
+        hipMalloc(&nv, bytes + pad) != hipSuccess) { (void)hipGetLastError(); return VV_OK; }
+    HIPCHK(c, hipMemsetAsync(nv, 0, bytes + pad, st));           // padding must be finite (weight-0 corners)
+    launch_repitch(c->d_vol, nv, dense_row, (size_t)c->ny, (size_t)c->nz, row, slice, st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipFree(c->d_vol));
+    c->d_vol = nv; c->row_pitch = row; c->slice_pitch = slice; c->alloc_bytes = bytes + pad;
+    return VV_OK;
+}
+
 // Builds the bricked / z-pair copy of the loaded volume if it is missing and HBM has room.
 // Returns true when the copy is usable afterwards.  
 static bool ensure_bricks(vv_context *c, hipStream_t st)
@@ -352,7 +393,7 @@ static bool ensure_bricks(vv_context *c, hipStream_t st)
         (void)hipGetLastError(); c->d_bricks = nullptr;
         return false;                                                     // no room: linear path
     }
-    launch_build_bricks(c->vtype, c->d_vol, c->d_bricks, c->nx, c->ny, c->nz, st);
+    launch_build_bricks(c->vtype, c->d_vol, c->row_pitch, c->slice_pitch, c->d_bricks, c->nx, c->ny, c->nz, st);
     if (hipMemsetAsync((char *)c->d_bricks + bb, 0, 16, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) {                         // later frames may come on another stream
         (void)hipGetLastError(); (void)hipFree(c->d_bricks); c->d_bricks = nullptr;
@@ -375,7 +416,7 @@ static bool ensure_zpair(vv_context *c, hipStream_t st)
         (void)hipGetLastError(); c->d_zpair = nullptr;
         return false;
     }
-    launch_build_zpair(c->vtype, c->d_vol, c->d_zpair, c->nx, c->ny, c->nz, st);
+    launch_build_zpair(c->vtype, c->d_vol, c->row_pitch, c->slice_pitch, c->d_zpair, c->nx, c->ny, c->nz, st);
     if (hipMemsetAsync((char *)c->d_zpair + zb, 0, 32, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         (void)hipGetLastError(); (void)hipFree(c->d_zpair); c->d_zpair = nullptr;
         return false;
@@ -389,9 +430,10 @@ static VolumeView view_of(const vv_context *c)
     VolumeView V;
     const uint32_t vsz = c->vtype == VV_VOXEL_F32 ? 4 : 1;
     V.data = c->d_vol; V.nx = c->nx; V.ny = c->ny; V.nz = c->nz;
-    V.row_bytes = (uint32_t)c->nx * vsz;
-    V.slice_bytes = (uint32_t)c->nx * (uint32_t)c->ny * vsz;
-    V.big = c->vol_bytes > (1ull << 32) || V.slice_bytes >= (1u << 24) || getenv("VV_FORCE_BIG") != nullptr;
+    (void)vsz;
+    V.row_bytes = (uint32_t)c->row_pitch;
+    V.slice_bytes = (uint32_t)c->slice_pitch;
+    V.big = c->slice_pitch * (size_t)c->nz > (1ull << 32) || V.slice_bytes >= (1u << 24) || getenv("VV_FORCE_BIG") != nullptr;
     V.bricks = nullptr; V.b_sy = 0; V.b_sz64 = 0;
     V.zpair = nullptr; V.zp_row_bytes = 0; V.zp_slab_bytes = 0;
     return V;
@@ -542,8 +584,8 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // Occupancy cap + gathers in flight (speed only; measured on MI355X):
     //   volume beyond the caches (> 1 GiB), aligned view : 2 blocks per CU, 3 samples per trip
     //   volume beyond the caches, rotated, linear layout : 1 block  per CU, 3 samples per trip
-    //   smaller volumes                                  : 3 blocks per CU, 3 (aligned) / 2 samples per trip
-    //   bricked copy (below)                             : 2 / 3 blocks per CU, 2 samples per trip
+    //   smaller volumes                                  : 4 blocks per CU, 3 (aligned) / 2 samples per trip
+    //   bricked copy (below)                             : 2 / 4 blocks per CU, 2 samples per trip
     // LDS per block = 4 KB table + reserve; 160 KB per CU.  VV_LDS_RESERVE / VV_UNROLL override.
     // XCD-aware block order: XCD k renders strips k, k+8, ... (each a full-width row of tiles), so
     // the tiles that share volume cache lines share an L2 (measured: -4 % on every workload)
@@ -553,7 +595,8 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // 3 samples per trip along the memory axis (A/B with repeats on MI355X: C3 -1.6 %, C2 -5.7 %, 512^3 -10 %,
     // u8 1024^3 -6.5 %; 4 per trip is no better), 2 on the bricked copy (3 there: +3.5 %)
     A.unroll = (A.strips.tile_log2w == 5 || beyond_caches) ? 3 : 2;
-    A.lds_reserve = !beyond_caches ? 49000 : (A.strips.tile_log2w == 5 ? 76000 : 155000);
+    // (re-swept with tools/ab_reserve.sh at the end of round 1: 4 blocks per CU for volumes up to 1 GiB)
+    A.lds_reserve = !beyond_caches ? 36000 : (A.strips.tile_log2w == 5 ? 76000 : 155000);
     if (const char *e = getenv("VV_UNROLL")) { int t = atoi(e); if (t == 2 || t == 3) A.unroll = t; }
     if (const char *e = getenv("VV_LDS_RESERVE")) { int t = atoi(e); if (t >= 0 && t <= 155 * 1024) A.lds_reserve = t; }
     // Bricked copy (speed only): off the memory axis the linear layout costs one cache line per lane
@@ -568,7 +611,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         A.V.bricks = c->d_bricks; A.V.b_sy = c->b_sy; A.V.b_sz64 = c->b_sz64;
         // measured (C3 rotated, 1024^3): 2 blocks per CU and 2 samples per trip: 3.64 -> 1.60 ms
         if (!getenv("VV_UNROLL")) A.unroll = 2;
-        if (!getenv("VV_LDS_RESERVE")) A.lds_reserve = beyond_caches ? 76000 : 49000;
+        if (!getenv("VV_LDS_RESERVE")) A.lds_reserve = beyond_caches ? 76000 : 36000;
     }
     // z-pair copy (speed only): along the memory axis the four corners (x..x+1, z..z+1) of a row come
     // from one gather (16 bytes for f32, 4 for u8), so a sample costs 2 gathers instead of 4 (f32) or 8

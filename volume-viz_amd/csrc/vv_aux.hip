@@ -340,7 +340,7 @@ size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_
 
 // one thread per stored element: E elements per brick row (BX voxels + halo [+ padding]), 16 rows per brick
 template <typename T, int E, int BX>
-__global__ __launch_bounds__(256) void brick_kernel(const T *__restrict__ in, T *__restrict__ out,
+__global__ __launch_bounds__(256) void brick_kernel(const T *__restrict__ in, size_t row_pitch, size_t slice_pitch, T *__restrict__ out,
                                                     int nx, int ny, int nz, size_t nbx, size_t nby, size_t total)
 {
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -348,11 +348,11 @@ __global__ __launch_bounds__(256) void brick_kernel(const T *__restrict__ in, T 
         const size_t b = t / (E * 16);
         const size_t bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
         const int x = min((int)bx * BX + e, nx - 1), y = min((int)by * 4 + (r & 3), ny - 1), z = min((int)bz * 4 + (r >> 2), nz - 1);
-        out[t] = e <= BX ? in[((size_t)z * ny + y) * nx + x] : T(0);
+        out[t] = e <= BX ? ((const T *)((const char *)in + (size_t)z * slice_pitch + (size_t)y * row_pitch))[x] : T(0);
     }
 }
 
-void launch_build_bricks(int vtype, const void *linear, void *bricks, int nx, int ny, int nz, hipStream_t s)
+void launch_build_bricks(int vtype, const void *linear, size_t row_pitch, size_t slice_pitch, void *bricks, int nx, int ny, int nz, hipStream_t s)
 {
     constexpr int FBX = BrickGeom<VV_VOXEL_F32>::bx;
     const size_t bxv = vtype == VV_VOXEL_F32 ? FBX : 4;
@@ -362,9 +362,31 @@ void launch_build_bricks(int vtype, const void *linear, void *bricks, int nx, in
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (vtype == VV_VOXEL_F32)
-        hipLaunchKernelGGL((brick_kernel<float, FBX + 1, FBX>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, (float *)bricks, nx, ny, nz, nbx, nby, total);
+        hipLaunchKernelGGL((brick_kernel<float, FBX + 1, FBX>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, row_pitch, slice_pitch, (float *)bricks, nx, ny, nz, nbx, nby, total);
     else
-        hipLaunchKernelGGL((brick_kernel<uint8_t, 8, 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, (uint8_t *)bricks, nx, ny, nz, nbx, nby, total);
+        hipLaunchKernelGGL((brick_kernel<uint8_t, 8, 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, row_pitch, slice_pitch, (uint8_t *)bricks, nx, ny, nz, nbx, nby, total);
+}
+
+// ---------------------------------------------------------------------------
+// dense -> pitched copy of the linear volume (vv_api.cpp finalize_layout); rows are multiples of 16 bytes
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void repitch_kernel(const uint4 *__restrict__ in, char *__restrict__ out, size_t row16, size_t ny,
+                                                      size_t row_pitch, size_t slice_pitch, size_t total)
+{
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t x = t % row16, r = t / row16, y = r % ny, z = r / ny;
+        *(uint4 *)(out + z * slice_pitch + y * row_pitch + x * 16) = in[t];
+    }
+}
+
+void launch_repitch(const void *dense, void *pitched, size_t row_bytes, size_t ny, size_t nz,
+                    size_t row_pitch, size_t slice_pitch, hipStream_t s)
+{
+    const size_t row16 = row_bytes / 16, total = row16 * ny * nz;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(repitch_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4 *)dense, (char *)pitched, row16, ny, row_pitch, slice_pitch, total);
 }
 
 // ---------------------------------------------------------------------------
@@ -381,7 +403,7 @@ size_t zpair_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *row_bytes, 
 
 // one thread per record; rows of `row_recs` records (u8 rows may end in one unused record of padding)
 template <typename T, typename T2>
-__global__ __launch_bounds__(256) void zpair_kernel(const T *__restrict__ in, T2 *__restrict__ out,
+__global__ __launch_bounds__(256) void zpair_kernel(const T *__restrict__ in, size_t row_pitch, size_t slice_pitch, T2 *__restrict__ out,
                                                     int nx, int ny, int nz, size_t row_recs, size_t total)
 {
     const size_t ry = (size_t)ny + 1;
@@ -389,13 +411,15 @@ __global__ __launch_bounds__(256) void zpair_kernel(const T *__restrict__ in, T2
         const int x = min((int)(t % row_recs), nx - 1);
         const size_t row = t / row_recs;
         const int y = min((int)(row % ry), ny - 1), z = (int)(row / ry);
-        const size_t i0 = ((size_t)z * ny + y) * nx + x, i1 = ((size_t)min(z + 1, nz - 1) * ny + y) * nx + x;
-        T2 r; r.x = in[i0]; r.y = in[i1];
+        const char *rowp = (const char *)in + (size_t)y * row_pitch;
+        T2 r;
+        r.x = ((const T *)(rowp + (size_t)z * slice_pitch))[x];
+        r.y = ((const T *)(rowp + (size_t)min(z + 1, nz - 1) * slice_pitch))[x];
         out[t] = r;
     }
 }
 
-void launch_build_zpair(int vtype, const void *linear, void *zpair, int nx, int ny, int nz, hipStream_t s)
+void launch_build_zpair(int vtype, const void *linear, size_t row_pitch, size_t slice_pitch, void *zpair, int nx, int ny, int nz, hipStream_t s)
 {
     uint32_t rb = 0, sb = 0;
     zpair_copy_bytes(vtype, nx, ny, nz, &rb, &sb);
@@ -404,9 +428,9 @@ void launch_build_zpair(int vtype, const void *linear, void *zpair, int nx, int 
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (vtype == VV_VOXEL_F32)
-        hipLaunchKernelGGL((zpair_kernel<float, float2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, (float2 *)zpair, nx, ny, nz, row_recs, total);
+        hipLaunchKernelGGL((zpair_kernel<float, float2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, row_pitch, slice_pitch, (float2 *)zpair, nx, ny, nz, row_recs, total);
     else
-        hipLaunchKernelGGL((zpair_kernel<uint8_t, uchar2>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, (uchar2 *)zpair, nx, ny, nz, row_recs, total);
+        hipLaunchKernelGGL((zpair_kernel<uint8_t, uchar2>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, row_pitch, slice_pitch, (uchar2 *)zpair, nx, ny, nz, row_recs, total);
 }
 
 // ---------------------------------------------------------------------------

@@ -33,9 +33,11 @@ void launch_raymarch_big(const MarchArgs &a, hipStream_t s);      // same kernel
 void launch_raymarch_bricked(const MarchArgs &a, hipStream_t s);  // same kernels on VolumeView::bricks
 void launch_raymarch_zpair(const MarchArgs &a, hipStream_t s);    // same kernels on VolumeView::zpair
 size_t zpair_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *row_bytes, uint32_t *slab_bytes);
-void launch_build_zpair(int vtype, const void *linear, void *zpair, int nx, int ny, int nz, hipStream_t s);
+void launch_build_zpair(int vtype, const void *linear, size_t row_pitch, size_t slice_pitch, void *zpair, int nx, int ny, int nz, hipStream_t s);
+void launch_repitch(const void *dense, void *pitched, size_t row_bytes /* multiple of 16 */, size_t ny, size_t nz,
+                    size_t row_pitch, size_t slice_pitch, hipStream_t s);
 size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_t *sz64);
-void launch_build_bricks(int vtype, const void *linear, void *bricks, int nx, int ny, int nz, hipStream_t s);
+void launch_build_bricks(int vtype, const void *linear, size_t row_pitch, size_t slice_pitch, void *bricks, int nx, int ny, int nz, hipStream_t s);
 void launch_raymarch_wstaged(const MarchArgs &a, hipStream_t s);  // wave-private LDS brick cache (no Phong)
 
 struct SliceArgs {
