@@ -349,19 +349,22 @@ int vv_volume_dims(const vv_context *c, int dims[3], int *vtype)
 // Pitch of the linear layout.  A row pitch that is a multiple of 1 KiB (1024^3 f32: 4 KiB) puts the four
 // rows a sample gathers from (y, y+1, z, z+1) on the same cache channels: the same frame takes 9 % longer
 // on a 1024^3 volume than on 1016^3 or 1032^3 (tools/ab_size.sh).  Such volumes are re-pitched on the
-// device after the upload: rows get 128 bytes of padding and, if a slice would still be a multiple of
-// 4 KiB, one extra row.  Needs the old and the new buffer side by side for a moment; if that does not
-// fit, the dense layout stays.  Measured on C3 (A/B on one box): 1.193 -> 1.142 ms although the padded
+// device after the upload: rows get 32 bytes of padding (swept 16...2048: 32, 48 and 96 are best, 128 is
+// 4 % behind) and, if a slice would still be a multiple of 4 KiB, one extra row.  Needs the old and the new buffer side by side for a moment; if that does not
+// fit, the dense layout stays.  Measured on C3 (A/B on one box): 1.19 -> 1.08 ms although the padded
 // 1024^3 volume is 4.4 GB and so takes the 64-bit slice addressing (+3 % by itself); nothing on the Phong
-// path; u8 volumes (1 KiB rows) gain nothing on the paths that still read the linear layout, so only f32
-// volumes are re-pitched.  VV_PITCH_PAD=0 disables.
+// (+3 % by itself); C3 + Phong 2.52 -> 2.46 ms; other sizes gain 1 % (not re-pitched); u8 volumes (1 KiB rows)
+// gain nothing on the paths that still read the linear layout, so only f32 volumes are re-pitched.
+// VV_PITCH_PAD=0 disables, VV_PITCH_PAD=<bytes> sets the padding, VV_PITCH_FORCE=1 pads any row length.
 static int finalize_layout(vv_context *c, hipStream_t st)
 {
-    if (const char *e = getenv("VV_PITCH_PAD")) if (atoi(e) == 0) return VV_OK;
+    size_t pad_bytes = 32;
+    if (const char *e = getenv("VV_PITCH_PAD")) { int t = atoi(e); if (t <= 0) return VV_OK; if (t >= 16 && t <= 4096 && t % 16 == 0) pad_bytes = (size_t)t; }
     if (c->vtype != VV_VOXEL_F32) return VV_OK;
     const size_t dense_row = c->row_pitch;
-    if (dense_row % 1024 != 0) return VV_OK;
-    const size_t row = dense_row + 128;
+    if (dense_row % 1024 != 0 && !getenv("VV_PITCH_FORCE")) return VV_OK;
+    if (dense_row % 16 != 0) return VV_OK;
+    const size_t row = dense_row + pad_bytes;
     size_t rows = (size_t)c->ny;
     if ((rows * row) % 4096 == 0) rows += 1;
     const size_t slice = rows * row;
