@@ -526,9 +526,9 @@ def test_prepare_layouts_and_device_bytes(ctx, monkeypatch):
 @pytest.mark.parametrize("dims,dtype", [((256, 9, 7), np.float32), ((256, 32, 5), np.float32), ((512, 3, 4), np.float32),
                                         ((1024, 5, 6), np.uint8), ((2048, 4, 3), np.uint8)])
 def test_padded_pitch_layout(ctx, dims, dtype, monkeypatch):
-    """f32 volumes whose rows are a multiple of 1 KiB are re-pitched on the device (rows + 32 B, and one
-    more row per slice if a slice would still be a multiple of 4 KiB): every consumer of the linear layout
-    and the builders of the two copies read it through the pitches (u8 volumes take the same code, dense)."""
+    """Volumes whose rows are a multiple of 1 KiB are re-pitched on the device (rows + 32 B, and one more
+    row per slice if a slice would still be a multiple of 4 KiB): every consumer of the linear layout and
+    the builders of the two copies read it through the pitches."""
     rng = np.random.default_rng(17)
     vol = rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)
     if dtype == np.float32:
@@ -536,8 +536,8 @@ def test_padded_pitch_layout(ctx, dims, dtype, monkeypatch):
     tf = vv.transfer_preset(vv.TF_ENGINE)
     ctx.load_volume(vol, tf)
     nx, ny, nz = dims
-    row = nx * vol.itemsize + (32 if dtype == np.float32 else 0)          # u8 volumes stay dense
-    rows = ny + (1 if dtype == np.float32 and (ny * row) % 4096 == 0 else 0)
+    row = nx * vol.itemsize + 32
+    rows = ny + (1 if (ny * row) % 4096 == 0 else 0)
     assert ctx.device_bytes()[0] == nz * rows * row + rows * row + row + 16
     opts = vv.make_options(step=1 / 60, count_samples=True)
     for env in ({}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}):

@@ -353,20 +353,21 @@ int vv_volume_dims(const vv_context *c, int dims[3], int *vtype)
 // 4 % behind) and, if a slice would still be a multiple of 4 KiB, one extra row.  Needs the old and the new buffer side by side for a moment; if that does not
 // fit, the dense layout stays.  Measured on C3 (A/B on one box): 1.19 -> 1.08 ms although the padded
 // 1024^3 volume is 4.4 GB and so takes the 64-bit slice addressing (+3 % by itself); nothing on the Phong
-// (+3 % by itself); C3 + Phong 2.52 -> 2.46 ms; other sizes gain 1 % (not re-pitched); u8 volumes (1 KiB rows)
-// gain nothing on the paths that still read the linear layout, so only f32 volumes are re-pitched.
+// (+3 % by itself); C3 + Phong 2.52 -> 2.46 ms; 512^3 0.71 -> 0.66 ms and C2 0.245 -> 0.224 ms on the linear path;
+// u8 1024^3 0.88 -> 0.77 ms on the linear path (= its z-pair copy), u8 + Phong -1 %; other edge lengths gain 1 %
+// (not re-pitched).
 // VV_PITCH_PAD=0 disables, VV_PITCH_PAD=<bytes> sets the padding, VV_PITCH_FORCE=1 pads any row length.
 static int finalize_layout(vv_context *c, hipStream_t st)
 {
     size_t pad_bytes = 32;
     if (const char *e = getenv("VV_PITCH_PAD")) { int t = atoi(e); if (t <= 0) return VV_OK; if (t >= 16 && t <= 4096 && t % 16 == 0) pad_bytes = (size_t)t; }
-    if (c->vtype != VV_VOXEL_F32) return VV_OK;
     const size_t dense_row = c->row_pitch;
     if (dense_row % 1024 != 0 && !getenv("VV_PITCH_FORCE")) return VV_OK;
     if (dense_row % 16 != 0) return VV_OK;
     const size_t row = dense_row + pad_bytes;
     size_t rows = (size_t)c->ny;
     if ((rows * row) % 4096 == 0) rows += 1;
+    if (const char *e = getenv("VV_PITCH_ROWS")) { int t = atoi(e); if (t >= 0 && t <= 64) rows = (size_t)c->ny + (size_t)t; }
     const size_t slice = rows * row;
     if (slice > 0xFFFFFFF0ull || row >= (1u << 24)) return VV_OK;
     const size_t bytes = slice * (size_t)c->nz, pad = slice + row + 16;
