@@ -7,6 +7,7 @@
 //                         n ellipsoids fused into one pass over the volume
 #include "vv_device.h"
 #include "vv_kernels.h"
+#include <cstdlib>
 
 namespace vv {
 
@@ -332,7 +333,13 @@ size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_
     const size_t brick = vtype == VV_VOXEL_F32 ? BrickGeom<VV_VOXEL_F32>::brick : BrickGeom<VV_VOXEL_U8>::brick;
     const size_t bxv = vtype == VV_VOXEL_F32 ? BrickGeom<VV_VOXEL_F32>::bx : BrickGeom<VV_VOXEL_U8>::bx;
     const size_t nbx = ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
-    const size_t row = nbx * brick, layer = nby * row;            // brick sizes are multiples of 64
+    size_t row = nbx * brick;                                     // brick sizes are multiples of 64
+    // a row of bricks that is a multiple of 4 KiB gets 64 bytes more (same cache-channel effect as the
+    // linear pitch, smaller: rotated C3 -1...-4 %, + Phong -4 %); VV_BRICK_PAD=<bytes, multiple of 64> / 0 overrides
+    size_t pad = (vtype == VV_VOXEL_F32 && row % 4096 == 0) ? 64 : 0;      // u8 bricks (one line each): +7 % with it
+    if (const char *e = getenv("VV_BRICK_PAD")) { int t = atoi(e); if (t >= 0 && t <= 4096 && t % 64 == 0) pad = (size_t)t; }
+    row += pad;
+    const size_t layer = nby * row;
     if (sy) *sy = (uint32_t)row;
     if (sz64) *sz64 = (uint32_t)(layer >> 6);
     return nbz * layer;
@@ -341,14 +348,16 @@ size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_
 // one thread per stored element: E elements per brick row (BX voxels + halo [+ padding]), 16 rows per brick
 template <typename T, int E, int BX>
 __global__ __launch_bounds__(256) void brick_kernel(const T *__restrict__ in, size_t row_pitch, size_t slice_pitch, T *__restrict__ out,
-                                                    int nx, int ny, int nz, size_t nbx, size_t nby, size_t total)
+                                                    int nx, int ny, int nz, size_t nbx, size_t nby, size_t total,
+                                                    size_t brow /* elements per row of bricks */, size_t blayer /* per layer */)
 {
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(t % E), r = (int)((t / E) % 16);
         const size_t b = t / (E * 16);
         const size_t bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
         const int x = min((int)bx * BX + e, nx - 1), y = min((int)by * 4 + (r & 3), ny - 1), z = min((int)bz * 4 + (r >> 2), nz - 1);
-        out[t] = e <= BX ? ((const T *)((const char *)in + (size_t)z * slice_pitch + (size_t)y * row_pitch))[x] : T(0);
+        out[bz * blayer + by * brow + bx * (size_t)(E * 16) + (size_t)(r * E + e)] =
+            e <= BX ? ((const T *)((const char *)in + (size_t)z * slice_pitch + (size_t)y * row_pitch))[x] : T(0);
     }
 }
 
@@ -359,12 +368,15 @@ void launch_build_bricks(int vtype, const void *linear, size_t row_pitch, size_t
     const size_t nbx = ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
     const size_t per_brick = vtype == VV_VOXEL_F32 ? 16 * (FBX + 1) : 128;
     const size_t total = nbx * nby * nbz * per_brick;
+    uint32_t sy = 0, sz64 = 0;
+    brick_copy_bytes(vtype, nx, ny, nz, &sy, &sz64);
+    const size_t esz = vtype == VV_VOXEL_F32 ? 4 : 1, brow = sy / esz, blayer = ((size_t)sz64 << 6) / esz;
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (vtype == VV_VOXEL_F32)
-        hipLaunchKernelGGL((brick_kernel<float, FBX + 1, FBX>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, row_pitch, slice_pitch, (float *)bricks, nx, ny, nz, nbx, nby, total);
+        hipLaunchKernelGGL((brick_kernel<float, FBX + 1, FBX>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, row_pitch, slice_pitch, (float *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
     else
-        hipLaunchKernelGGL((brick_kernel<uint8_t, 8, 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, row_pitch, slice_pitch, (uint8_t *)bricks, nx, ny, nz, nbx, nby, total);
+        hipLaunchKernelGGL((brick_kernel<uint8_t, 8, 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, row_pitch, slice_pitch, (uint8_t *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
 }
 
 // ---------------------------------------------------------------------------
@@ -395,7 +407,9 @@ void launch_repitch(const void *dense, void *pitched, size_t row_bytes, size_t n
 size_t zpair_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *row_bytes, uint32_t *slab_bytes)
 {
     const size_t rec = vtype == VV_VOXEL_F32 ? 8 : 2;
-    const size_t row = (((size_t)nx + 1) * rec + 3) & ~(size_t)3, slab = ((size_t)ny + 1) * row;
+    size_t row = (((size_t)nx + 1) * rec + 3) & ~(size_t)3;
+    if (const char *e = getenv("VV_ZPAIR_PAD")) { int t = atoi(e); if (t > 0 && t <= 4096 && t % 8 == 0) row += (size_t)t; }   // experiment knob (no effect measured)
+    const size_t slab = ((size_t)ny + 1) * row;
     if (row_bytes) *row_bytes = (uint32_t)row;
     if (slab_bytes) *slab_bytes = (uint32_t)slab;
     return slab * (size_t)nz;
