@@ -317,9 +317,16 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
         load_rows<VOXEL>((const char *)V.data, V.row_bytes, V.slice_bytes, ix,
                          __umul24(iy, V.row_bytes) + __umul24(iz, V.slice_bytes), C);
     } else if constexpr (LAYOUT == LAYOUT_LINEAR_BIG) {
-        // volumes above 4 GiB (separate kernel instantiations): 64-bit slice base per lane
-        const char *zb = (const char *)V.data + (uint64_t)iz * V.slice_bytes;
-        load_rows<VOXEL>(zb, V.row_bytes, V.slice_bytes, ix, __umul24(iy, V.row_bytes), C);
+        // volumes above 4 GiB (separate kernel instantiations): one 64-bit address per lane for the
+        // corner row, the three others are 64-bit additions of the uniform row / slice pitches
+        const uint32_t vsz = VOXEL == VV_VOXEL_F32 ? 4u : 1u;
+        const char *zb = (const char *)V.data + (uint64_t)iz * V.slice_bytes + (__umul24(iy, V.row_bytes) + ix * vsz);
+        if constexpr (VOXEL == VV_VOXEL_F32) load_rows<VOXEL>(zb, V.row_bytes, V.slice_bytes, 0u, 0u, C);
+        else {
+            // u8: load_rows wants the x index for its aligned-dword trick
+            const char *zr = (const char *)V.data + (uint64_t)iz * V.slice_bytes;
+            load_rows<VOXEL>(zr, V.row_bytes, V.slice_bytes, ix, __umul24(iy, V.row_bytes), C);
+        }
     } else {
         // bricked copy: the rows y / y+1 and the slices z / z+1 of a sample sit in the same brick
         // unless (y & 3) == 3 resp. (z & 3) == 3; the x pair always does (halo voxel)
