@@ -614,6 +614,42 @@ def test_render_full_size_properties(ctx):
     assert np.array_equal(parts, full) and total == n_full
 
 
+def test_c3_headline_frames_match_oracle(ctx):
+    """The bench.py workload itself (BASELINE config C3: 1024^3 f32 noise volume, 1920x1080, step 1/512,
+    colour-ramp table, reference ERT), whole frames, against the oracle on the downloaded volume: the
+    camera along the memory axis (re-pitched linear layout, 64-bit slice addressing), the same with
+    Phong, and the rotated camera of SURVEY 8d (bricked copy).  Every pixel and the sample counts."""
+    import torch
+    sys_path_bench = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(sys_path_bench, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    n, W, H = 1024, 1920, 1080
+    dev = torch.device("cuda", 0)
+    v8 = torch.empty(n ** 3, dtype=torch.uint8, device=dev)
+    ctx.generate_noise_device(v8.data_ptr(), n, n, n, 0x9E3779B9)
+    v32 = torch.empty(n ** 3, dtype=torch.float32, device=dev)
+    ctx.promote_device(v8.data_ptr(), v32.data_ptr(), n ** 3)
+    tf = bench.ramp_tf()
+    ctx.load_volume_device(v32.data_ptr(), vv.VOXEL_F32, n, n, n, tf)
+    torch.cuda.synchronize()
+    host = v32.cpu().numpy().reshape(n, n, n)
+    del v8, v32
+    torch.cuda.empty_cache()
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    for cam, phong, slot in ((vv.Camera(), False, None), (vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5), False, 2), (vv.Camera(), True, None)):
+        opts = vv.make_options(step=1 / 512, count_samples=True)
+        got = ctx.render(W, H, cam, phong=phong, options=opts)
+        n_got = ctx.last_sample_count()
+        if slot is not None:
+            assert ctx.debug_counters()[slot] > 0
+        want, n_want = O.render(host, tf, W, H, cam, phong=phong, options=vv.make_options(step=1 / 512), threads=threads)
+        assert_frames_close(got, want, f"C3 frame phong={phong} layout={slot}")
+        assert n_got == n_want
+        assert (got[..., 3] > 0).mean() > 0.3
+    ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
+
+
 def test_streamed_upload_equals_direct_load(ctx, tmp_path, golden_dir):
     """vv_load_volume_stream_* / vv_load_volume_t3d: same frames as vv_load_volume_*."""
     vol = O.noise_u8(40, 36, 50, 3)
