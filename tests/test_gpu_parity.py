@@ -615,7 +615,7 @@ def test_render_full_size_properties(ctx):
 
 
 def test_c3_headline_frames_match_oracle(ctx):
-    """The bench.py workload itself (BASELINE config C3: 1024^3 f32 noise volume, 1920x1080, step 1/512,
+    """The bench.py workloads themselves (BASELINE config C3: 1024^3 f32 noise volume, 1920x1080, step 1/512,
     colour-ramp table, reference ERT), whole frames, against the oracle on the downloaded volume: the
     camera along the memory axis (re-pitched linear layout, 64-bit slice addressing), the same with
     Phong, and the rotated camera of SURVEY 8d (bricked copy).  Every pixel and the sample counts."""
@@ -647,6 +647,15 @@ def test_c3_headline_frames_match_oracle(ctx):
         assert_frames_close(got, want, f"C3 frame phong={phong} layout={slot}")
         assert n_got == n_want
         assert (got[..., 3] > 0).mean() > 0.3
+    # one rank's share of the 8-GPU frame (BASELINE config C4: 3840x2160, step 1/1024, bands of 4 slab
+    # rows dealt round-robin): the shard predicate at full size, rows of other ranks untouched
+    W4, H4 = bench.FRAMES[8][0], bench.FRAMES[8][1]
+    sopts = dict(step=1.0 / bench.FRAMES[8][2], shard=(4, 8, 3))
+    got = ctx.render(W4, H4, vv.Camera(), options=vv.make_options(count_samples=True, **sopts), fill=0x77)
+    n_got = ctx.last_sample_count()
+    want, n_want = O.render(host, tf, W4, H4, vv.Camera(), options=vv.make_options(**sopts), fill=0x77, threads=threads)
+    assert_frames_close(got, want, "C4 shard 3 of 8")
+    assert n_got == n_want and n_got > 10_000_000
     ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
 
 
