@@ -303,18 +303,22 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
     __shared__ uint8_t cache[kCacheDepth][256];
     __shared__ float q255[256];              // q / 255.f for every byte q, by the same IEEE division
     __shared__ int any_live;
+    // XCD-aware order (speed only, as in march_kernel): linear block L runs on XCD L % 8; XCD k takes the
+    // grid rows k, k+8, ... so that the slabs of one row, which share volume lines, share an L2
+    const int gx = ((int)blockIdx.x >> 3) % P.nbx, gy = (((int)blockIdx.x >> 3) / P.nbx) * 8 + ((int)blockIdx.x & 7);
+    if (gy > M.n_regular) return;                              // block-uniform, before any barrier
     stage_tf(lds_tf, tf);
     // kernel.cu:175-177 divides six cached bytes by 255.f per shaded sample; a correctly rounded
     // division is ~10 instructions, a table look-up of the same quotient is one LDS read
     q255[threadIdx.x] = (float)threadIdx.x / 255.f;      // visible after the barriers of the reduction below
 
-    // blockIdx.y -> slab row of this shard; the last grid row is the "extra" slab row
+    // grid row gy -> slab row of this shard; the last grid row is the "extra" slab row
     // nby-1 that re-writes pixel row H-2 when H == 1 (mod 14) (pin 10): it travels with
     // the shard that owns pixel row H-2.
-    const int bx = blockIdx.x;
+    const int bx = gx;
     int by;
-    if ((int)blockIdx.y == M.n_regular) { if (!P.conflict_y) return; by = P.nby - 1; }
-    else by = M.r0 + ((int)blockIdx.y / M.band) * M.band_stride + ((int)blockIdx.y % M.band);
+    if (gy == M.n_regular) { if (!P.conflict_y) return; by = P.nby - 1; }
+    else by = M.r0 + (gy / M.band) * M.band_stride + (gy % M.band);
     if (by >= P.nby) return;                                   // block-uniform
     {
         // ownership is decided on the pixel rows this slab row writes
@@ -501,7 +505,8 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
 template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 static void launch_phong(const MarchArgs &a, hipStream_t s)
 {
-    dim3 grid(a.P.nbx, a.slabs.n_regular + 1);
+    const int rows = a.slabs.n_regular + 1;                   // grid rows, dealt to the 8 XCDs round-robin
+    dim3 grid((unsigned)(((rows + 7) / 8) * 8 * a.P.nbx));
     hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), (size_t)a.lds_reserve_phong, s,
                        a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
 }
