@@ -596,11 +596,25 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     A.strips.xcd_band = 1;
     if (const char *e = getenv("VV_XCD_BAND")) { int t = atoi(e); if (t >= 0 && t <= 64) A.strips.xcd_band = t; }
     const bool beyond_caches = c->vol_bytes > (1ull << 30);
+    // Sampling density: voxels of volume per sample = (voxels per step) x (voxels per pixel)^2 at the
+    // cube centre.  Sparse rays (C3 at 1080p: 4.9) reuse little of a cache line and want few waves on a CU's
+    // L1; the denser frames of the multi-GPU configurations (2716x1528: 2.5, 3840x2160: 1.2, and 0.6 at
+    // step 1/1024) want more: the whole 3840x2160 / 1024-step frame takes 3.51 ms with 2 blocks per CU and
+    // 2.71 ms with 4 (tools/sweep.sh --frame-of 8; bricked copy 4.71 -> 3.34 ms, Phong 9.0 -> 7.9 ms).
+    float density = 1e9f;                           // unknown ray source: treat as sparse
+    if (rays->mode == VV_RAYS_ANALYTIC && H > 0) {
+        const float dist = vlen_h(cam->origin[0], cam->origin[1], cam->origin[2]);
+        const float vpw = cbrtf(((float)c->nx / (2.f * P.scale[0])) * ((float)c->ny / (2.f * P.scale[1])) * ((float)c->nz / (2.f * P.scale[2])));
+        const float px_vox = 2.f * P.tan_half_y * dist / (float)H * vpw;
+        const float step_vox = fmaxf(P.step[0] * c->nx, fmaxf(P.step[1] * c->ny, P.step[2] * c->nz));
+        if (std::isfinite(px_vox) && std::isfinite(step_vox) && px_vox > 0.f && step_vox > 0.f) density = step_vox * px_vox * px_vox;
+    }
+    const int big_reserve = density > 3.5f ? 76000 : (density > 1.8f ? 49000 : 36000);   // 2 / 3 / 4 blocks per CU
     // 3 samples per trip along the memory axis (A/B with repeats on MI355X: C3 -1.6 %, C2 -5.7 %, 512^3 -10 %,
     // u8 1024^3 -6.5 %; 4 per trip is no better), 2 on the bricked copy (3 there: +3.5 %)
     A.unroll = (A.strips.tile_log2w == 5 || beyond_caches) ? 3 : 2;
     // (re-swept with tools/ab_reserve.sh at the end of round 1: 4 blocks per CU for volumes up to 1 GiB)
-    A.lds_reserve = !beyond_caches ? 36000 : (A.strips.tile_log2w == 5 ? 76000 : 155000);
+    A.lds_reserve = !beyond_caches ? 36000 : (A.strips.tile_log2w == 5 ? big_reserve : 155000);
     if (const char *e = getenv("VV_UNROLL")) { int t = atoi(e); if (t == 2 || t == 3) A.unroll = t; }
     if (const char *e = getenv("VV_LDS_RESERVE")) { int t = atoi(e); if (t >= 0 && t <= 155 * 1024) A.lds_reserve = t; }
     // Bricked copy (speed only): off the memory axis the linear layout costs one cache line per lane
@@ -615,7 +629,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         A.V.bricks = c->d_bricks; A.V.b_sy = c->b_sy; A.V.b_sz64 = c->b_sz64;
         // measured (C3 rotated, 1024^3): 2 blocks per CU and 2 samples per trip: 3.64 -> 1.60 ms
         if (!getenv("VV_UNROLL")) A.unroll = 2;
-        if (!getenv("VV_LDS_RESERVE")) A.lds_reserve = beyond_caches ? 76000 : 36000;
+        if (!getenv("VV_LDS_RESERVE")) A.lds_reserve = beyond_caches ? big_reserve : 36000;
     }
     // z-pair copy (speed only): along the memory axis the four corners (x..x+1, z..z+1) of a row come
     // from one gather (16 bytes for f32, 4 for u8), so a sample costs 2 gathers instead of 4 (f32) or 8
@@ -632,7 +646,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // Phong kernel: 14.3 KB of LDS per block + this reserve.  Measured (tools/ab_phong.sh): volumes up to
     // 1 GiB like 5 blocks per CU (C2 0.54 -> 0.47 ms against no cap, u8 1024^3 1.88 -> 1.78), the 4 GiB
     // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)
-    A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : (beyond_caches ? 30000 : 13000);
+    A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f) ? 30000 : 13000);
     if (const char *e = getenv("VV_LDS_RESERVE_PHONG")) { int t = atoi(e); if (t >= 0 && t <= 146 * 1024) A.lds_reserve_phong = t; }
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
