@@ -164,8 +164,10 @@ def main():
     ctx.render_device(W, H, cam, frame.data_ptr(), options=iopts, stream=stream, phong=args.phong)
     torch.cuda.synchronize()
     samples = ctx.last_sample_count()
-    if os.environ.get("VV_STATS"):
-        print("stats", ctx.debug_counters().tolist(), file=sys.stderr)
+    if os.environ.get("VV_STATS"):      # developer statistics from a counters-only frame (no brick marking)
+        ctx.render_device(W, H, cam, frame.data_ptr(), options=vv.make_options(count_samples=True, **base), stream=stream, phong=args.phong)
+        torch.cuda.synchronize()
+        print("stats", ctx.debug_counters().tolist(), "instrumented frame ms", ctx.last_frame_ms(), file=sys.stderr)
     words = bitmap.cpu().numpy().view(np.uint32)
     bricks = int(np.unpackbits(words.view(np.uint8)).sum())
     rows_owned = len(sharding.owned_rows(H, world, rank))

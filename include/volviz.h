@@ -293,7 +293,11 @@ int  vv_device_bytes(const vv_context *ctx, unsigned long long out[4]);
 /* ---- metrics (the reference only has a clock() overlay) ---------------- */
 float              vv_last_frame_ms(const vv_context *ctx);      /* hipEvent time of the last vv_render */
 unsigned long long vv_last_sample_count(vv_context *ctx);        /* executed samples, if count_samples */
-int                vv_debug_counters(vv_context *ctx, unsigned long long out[8]);   /* developer statistics */
+int                vv_debug_counters(vv_context *ctx, unsigned long long out[16]);  /* developer statistics of the last instrumented frame */
+/* developer trace of the sweep kernel's blocks of the last frame rendered with VV_SWEEP_TRACE=1 in the environment:
+ * 8 words per block (start, march start, end in 10 ns ticks; hardware ids; tile; slice range; chunks; valid).
+ * Returns the number of blocks copied. */
+int                vv_debug_sweep_trace(vv_context *ctx, unsigned long long *out, int max_blocks);
 int                vv_volume_dims(const vv_context *ctx, int dims[3], int *voxel_type);
 
 #ifdef __cplusplus

@@ -430,6 +430,61 @@ def test_staged_kernel_is_bit_identical(ctx, view, monkeypatch):
     assert ctx.debug_counters()[1] > 0
 
 
+SWEEP_CAMS = {
+    "z+": vv.Camera(),                                                             # along +z (the headline view)
+    "z-": vv.Camera(origin=(0.3, 0.2, 4.0)),                                       # along -z
+    "y+": vv.Camera(origin=(0.5, -3.5, 0.4), up=(0.0, 0.0, 1.0)),                  # along +y: slices are x-z planes
+    "y-": vv.Camera(origin=(-0.3, 3.8, -0.2), up=(0.0, 0.0, 1.0)),
+    "tilt": vv.Camera.orbit(4.0, 1.2, -1.3),                                       # z+ with both minor slopes
+}
+
+
+@pytest.mark.parametrize("view", list(SWEEP_CAMS))
+def test_sweep_kernel_is_bit_identical(ctx, view, monkeypatch):
+    """The slab sweep (vv_sweep.hip: volume streamed through an LDS slice ring by loader waves, VV_SWEEP=1
+    forces it wherever it qualifies) must give the oracle's frames and sample counts: both sweep axes and
+    directions, ragged volume sizes, both ERT modes and filters, scaled cubes, sharded rows; the instrumented
+    build also checks that no sample fell outside the slices' images in LDS and that no watchdog fired."""
+    monkeypatch.setenv("VV_SWEEP", "1")
+    cam = SWEEP_CAMS[view]
+    cases = (((64, 64, 64), vv.TF_ENGINE, 1 / 64, 150, 97), ((48, 40, 36), vv.TF_HEAD, 1 / 50, 150, 97),
+             ((36, 70, 20), vv.TF_ENGINE, 1 / 40, 97, 150), ((128, 128, 128), vv.TF_ENGINE, 1 / 128, 320, 200),
+             ((20, 16, 200), vv.TF_HEAD, 1 / 100, 64, 48))
+    for dims, tfp, step, W, H in cases:
+        vol = (O.noise_u8(*dims, 7) if dims[0] != 128 else O.draw_default_brain(*dims)).astype(np.float32) / np.float32(255)
+        tf = vv.transfer_preset(tfp)
+        ctx.load_volume(vol, tf)
+        for ert, filt in ((vv.ERT_REFERENCE, vv.FILTER_TEX8), (vv.ERT_TRUE, vv.FILTER_EXACT)):
+            o = dict(step=step, ert_mode=ert, ert_threshold=0.9, filter=filt)
+            got = ctx.render(W, H, cam, options=vv.make_options(count_samples=True, **o), fill=0x11)
+            n_got = ctx.last_sample_count()
+            cnt = ctx.debug_counters()
+            want, n = O.render(vol, tf, W, H, cam, options=vv.make_options(**o), fill=0x11)
+            what = f"sweep {view} {dims} step {step:.4f} ert{ert} filt{filt}"
+            # (the thin 20 x 16 x 200 volume qualifies only along z: in voxel units its rays are too flat along y)
+            # (the ragged volumes qualify only for some views: in voxel units their rays may be too flat along the sweep axis)
+            assert cnt[5] > 0 or n == 0 or dims[0] != dims[2], f"{what}: the sweep kernel did not run"
+            assert cnt[4] == 0 and cnt[7] == 0, f"{what}: {cnt[4]} samples outside the LDS images, {cnt[7]} blocks flagged an error"
+            assert_frames_close(got, want, what)
+            assert n_got == n, what
+            got2 = ctx.render(W, H, cam, options=vv.make_options(**o), fill=0x11)            # the uninstrumented build
+            assert np.array_equal(got2, want), what + " (uninstrumented)"
+    # scaled cube and a shard of the frame
+    vol = O.noise_u8(40, 56, 48, 3).astype(np.float32) / np.float32(255)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    cam_s = vv.Camera(origin=cam.origin, up=cam.up, scale=(0.8, 1.0, 1.57))
+    for shard in (None, (4, 3, 1)):
+        o = vv.make_options(step=1 / 64, count_samples=True, shard=shard)
+        got = ctx.render(200, 160, cam_s, options=o, fill=0x22)
+        n_got = ctx.last_sample_count()
+        cnt = ctx.debug_counters()
+        want, n = O.render(vol, tf, 200, 160, cam_s, options=o, fill=0x22)
+        assert cnt[4] == 0 and cnt[7] == 0
+        assert_frames_close(got, want, f"sweep {view} scaled shard={shard}")
+        assert n_got == n
+
+
 @pytest.mark.parametrize("seed", range(0, 48, 3))
 def test_bricked_copy_is_bit_identical(ctx, seed, monkeypatch):
     """The 4x4x4-brick copy of the volume (used by default for views off the memory axis on volumes

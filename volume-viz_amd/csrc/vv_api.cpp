@@ -38,6 +38,7 @@ struct vv_context {
     float *d_slice = nullptr; size_t slice_cap = 0;
     float *d_gen = nullptr; size_t gen_cap = 0;       // per-axis tables of the ellipsoid generator
     unsigned long long *d_counter = nullptr;
+    unsigned long long *d_trace = nullptr; int trace_blocks = 0;      // developer trace of the sweep kernel (VV_SWEEP_TRACE=1)
     bool counter_valid = false;
     // streamed upload
     hipStream_t copy_stream = nullptr;
@@ -97,7 +98,7 @@ int vv_init(int device, vv_context **out)
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc((void **)&c->d_counter, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&c->d_counter, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&c->d_tf, 256 * sizeof(float4)) != hipSuccess) {
         delete c;
         return fail(nullptr, VV_ERR_DEVICE, "vv_init: device set-up failed");
@@ -120,6 +121,7 @@ int vv_shutdown(vv_context *c)
     if (c->d_slice) hipFree(c->d_slice);
     if (c->d_gen) hipFree(c->d_gen);
     if (c->d_counter) hipFree(c->d_counter);
+    if (c->d_trace) hipFree(c->d_trace);
     for (int i = 0; i < 2; ++i) {
         if (c->pin[i]) hipHostFree(c->pin[i]);
         if (c->pin_ev[i]) hipEventDestroy(c->pin_ev[i]);
@@ -164,7 +166,7 @@ static int install_volume(vv_context *c, const void *src, bool src_on_device, in
     HIPCHK(c, hipSetDevice(c->device));
     // one slice + one row + 16 bytes of zero padding: weight-0 corner fetches of edge
     // samples land here instead of needing index clamps (see vv_device.h VolumeView)
-    const size_t pad = (size_t)nx * ny * vsz + (size_t)nx * vsz + 16;
+    const size_t pad = (size_t)nx * ny * vsz + 2 * (size_t)nx * vsz + 4096;   // (the sweep's loaders read whole 128-byte cells: up to one more row + a cell)
     drop_bricks(c);
     if (c->d_vol) { HIPCHK(c, hipFree(c->d_vol)); c->d_vol = nullptr; }   // the reference leaks here
     HIPCHK(c, hipMalloc(&c->d_vol, bytes + pad));
@@ -210,6 +212,15 @@ int vv_prepare_layouts(vv_context *c, int which, void *stream)
     return built;
 }
 
+int vv_debug_sweep_trace(vv_context *c, unsigned long long *out, int max_blocks)
+{
+    if (!c || !out || !c->d_trace) return VV_ERR_INVALID;
+    const int n = c->trace_blocks < max_blocks ? c->trace_blocks : max_blocks;
+    if (hipDeviceSynchronize() != hipSuccess) return VV_ERR_DEVICE;
+    if (hipMemcpy(out, c->d_trace, 64ull * n, hipMemcpyDeviceToHost) != hipSuccess) return VV_ERR_DEVICE;
+    return n;
+}
+
 int vv_device_bytes(const vv_context *c, unsigned long long out[4])
 {
     if (!c || !out) return VV_ERR_INVALID;
@@ -220,11 +231,11 @@ int vv_device_bytes(const vv_context *c, unsigned long long out[4])
     return VV_OK;
 }
 
-int vv_debug_counters(vv_context *c, unsigned long long out[8])
+int vv_debug_counters(vv_context *c, unsigned long long out[16])
 {
     if (!c || !out || !c->counter_valid) return VV_ERR_INVALID;
     if (hipEventSynchronize(c->ev1) != hipSuccess) return VV_ERR_DEVICE;
-    if (hipMemcpy(out, c->d_counter, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return VV_ERR_DEVICE;
+    if (hipMemcpy(out, c->d_counter, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return VV_ERR_DEVICE;
     return VV_OK;
 }
 
@@ -241,7 +252,7 @@ int vv_load_volume_stream_begin(vv_context *c, int vtype, int nx, int ny, int nz
     if ((size_t)nx * vsz >= (1u << 24) || ny >= (1 << 24) || nz >= (1 << 24))
         return fail(c, VV_ERR_INVALID, "stream_begin: a volume row must be below 16 MiB and each dimension below 2^24");
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t bytes = (size_t)nx * ny * nz * vsz, pad = (size_t)nx * ny * vsz + (size_t)nx * vsz + 16;
+    const size_t bytes = (size_t)nx * ny * nz * vsz, pad = (size_t)nx * ny * vsz + 2 * (size_t)nx * vsz + 4096;
     drop_bricks(c);
     if (c->d_vol) { HIPCHK(c, hipFree(c->d_vol)); c->d_vol = nullptr; }
     HIPCHK(c, hipMalloc(&c->d_vol, bytes + pad));
@@ -370,7 +381,7 @@ static int finalize_layout(vv_context *c, hipStream_t st)
     if (const char *e = getenv("VV_PITCH_ROWS")) { int t = atoi(e); if (t >= 0 && t <= 64) rows = (size_t)c->ny + (size_t)t; }
     const size_t slice = rows * row;
     if (slice > 0xFFFFFFF0ull || row >= (1u << 24)) return VV_OK;
-    const size_t bytes = slice * (size_t)c->nz, pad = slice + row + 16;
+    const size_t bytes = slice * (size_t)c->nz, pad = slice + 2 * row + 4096;
     size_t free_b = 0, total_b = 0;
     void *nv = nullptr;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + pad + (512ull << 20) ||
@@ -667,7 +678,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     A.pixels = (uint32_t *)d_out;
     if (((uintptr_t)d_out & 3) != 0) return fail(c, VV_ERR_INVALID, "vv_render: output buffer must be 4-byte aligned");
 
-    if (A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter, 0, 8 * sizeof(unsigned long long), st));
+    if (A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), st));
     c->counter_valid = A.instr;
     HIPCHK(c, hipEventRecord(c->ev0, st));
     if (A.phong) {
@@ -680,7 +691,21 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         // staged design of DESIGN.md section 4.  It needs 16-byte aligned rows and <= 4 GiB.
         bool wst = false;
         if (const char *e = getenv("VV_WSTAGED")) wst = atoi(e) != 0 && (A.V.row_bytes % 16u) == 0 && !A.V.big;
-        if (wst) launch_raymarch_wstaged(A, st);
+        // Slab sweep (vv_sweep.hip): the volume streamed through LDS by dedicated loader waves.
+        bool sweep = false;
+        if (const char *e = getenv("VV_SWEEP")) sweep = atoi(e) != 0;
+        if (sweep && !wst) {
+            const int own_bands = s_count > 1 ? A.strips.n_strips / A.strips.strips_per_band : 0;
+            plan_sweep(A, A.strips.y0, A.strips.n_strips * 8, own_bands);
+            sweep = A.sweep.enabled != 0;
+        }
+        if (sweep && !wst && getenv("VV_SWEEP_TRACE")) {
+            const int nb = ((A.sweep.nty + 7) / 8) * 8 * A.sweep.ntx;
+            if (!c->d_trace) { if (hipMalloc((void **)&c->d_trace, 8ull * 8 * 65536) != hipSuccess) c->d_trace = nullptr; }
+            if (c->d_trace && nb <= 65536) { HIPCHK(c, hipMemsetAsync(c->d_trace, 0, 64ull * nb, st)); A.sweep.trace = c->d_trace; c->trace_blocks = nb; }
+        }
+        if (sweep && !wst) launch_raymarch_sweep(A, st);
+        else if (wst) launch_raymarch_wstaged(A, st);
         else if (A.V.bricks) launch_raymarch_bricked(A, st);
         else if (A.V.zpair) launch_raymarch_zpair(A, st);
         else if (A.V.big) launch_raymarch_big(A, st);

@@ -9,6 +9,27 @@ namespace vv {
 struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips, xcd_band; };
 struct SlabMap  { int r0, band, band_stride, n_regular; };
 
+// Slab sweep (vv_sweep.hip): a block of nc = wx * wy consumer waves (32 x 2 pixels each) + `nl` loader waves owns a
+// (32 wx) x (2 wy) pixel tile and walks the volume slice by slice along the sweep axis (y or z; rows along x are
+// contiguous in both cases).
+struct SweepArgs {
+    int enabled;
+    int major;             // 1: slices are x-z planes (sweep along y); 2: x-y planes (sweep along z)
+    int sgn;               // +1: slice index grows along every ray, -1: it falls
+    int wx, wy, nc, nl;    // consumer waves across / down the tile, their product, loader waves per block
+    int ntx, nty;          // tile grid
+    int y0, rows_per_band, band_stride_px;   // pixel row of tile row t: y0 + (t / rows_per_band) * band_stride_px + (t % rows_per_band) * 2 wy
+    int group;             // slices per loader group (one footprint, one allocation, one confirmation)
+    int depth;             // groups a loader wave keeps pending
+    int lead;              // > 0: one more wave prefetches the slices `lead` beyond the ring into L2
+    int pxc, ry, ring;     // LDS image of a slice: ry rows of pxc 128-byte cells; `ring` slots (power of two)
+    int slot_bytes;        // pxc * 128 * ry
+    int lds_bytes;         // dynamic LDS of the launch
+    unsigned long long *trace;   // developer trace (VV_SWEEP_TRACE=1): 8 words per block, or NULL
+    const int *order;      // optional tile order (device), n_order entries; NULL = XCD-interleaved raster order
+    int n_order;
+};
+
 struct MarchArgs {
     FrameParams P;
     VolumeView  V;
@@ -17,6 +38,7 @@ struct MarchArgs {
     int lds_reserve;            // march_kernel: dynamic LDS bytes reserved only to cap blocks per CU
     int unroll;                 // march_kernel: samples per loop trip (2 or 3)
     int lds_reserve_phong;      // march_phong_kernel: same occupancy cap (its own LDS is 13.3 KB)
+    SweepArgs sweep;                   // sweep_kernel (vv_sweep.hip)
     StripMap strips;                   // march_kernel: strips of 8 pixel rows (n_strips of them)
     SlabMap slabs;                     // march_phong_kernel grid.y = n_regular + 1
     const float4 *tf;           // device, 256 entries
@@ -39,6 +61,9 @@ void launch_repitch(const void *dense, void *pitched, size_t row_bytes /* multip
 size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_t *sz64);
 void launch_build_bricks(int vtype, const void *linear, size_t row_pitch, size_t slice_pitch, void *bricks, int nx, int ny, int nz, hipStream_t s);
 void launch_raymarch_wstaged(const MarchArgs &a, hipStream_t s);  // wave-private LDS brick cache (no Phong)
+void launch_raymarch_sweep(const MarchArgs &a, hipStream_t s);    // block-wide slab sweep, LDS slice ring filled by LDS-DMA (f32, no Phong)
+// host-side sizing of the sweep for a frame (fills a.sweep; enabled = 0 if the frame does not qualify)
+void plan_sweep(MarchArgs &a, int first_tile_row_px, int n_pixel_rows, int own_bands);
 
 struct SliceArgs {
     VolumeView V; int V_type; bool tex8;

@@ -1,0 +1,753 @@
+// vv_sweep.hip -- block-wide slab sweep: the ray march with the volume streamed through LDS (gfx950).
+//
+// Replaces kernel<SLICE_NONE> + mainLoop (kernel.cu:203-367) for unshaded frames whose rays all cross the
+// volume's x-y (or x-z) planes in the same direction.  Same arithmetic per sample as march_kernel
+// (vv_raymarch.hip), so frames stay bit-identical; what changes is where the eight corners come from.
+//
+// march_kernel gathers them from HBM through the 32 KB L1 (4 wave-wide gathers per sample, 16 cycles of
+// address pipeline each, stalled by every miss).  Here a block of up to 1024 threads owns a wide, short pixel
+// tile (e.g. 96 x 8):
+//   * nc = wx * wy consumer waves, 32 x 2 pixels each, keep one ray per lane in registers;
+//   * nl loader waves walk the slices k = kmin .. kmax the tile's rays cross, in the order the rays
+//     cross them, and copy each slice's footprint of the tile -- the bounding box of the tile's
+//     frustum in that slice, a few hundred voxels wide and two dozen rows high -- HBM -> LDS with
+//     `global_load_lds_dwordx4` (whole 128-byte cells, one image row per wave instruction, no registers)
+//     into a ring of `ring` slice slots;
+//   * a consumer lane takes its next sample as soon as the two slices it interpolates between have
+//     landed (four 8-byte LDS reads), at its own pace: lanes are not in lock step, so a wave needs
+//     no common slab of slices and stalls only when the loaders are behind;
+//   * flags in LDS replace barriers: `loaded` (slices landed, written by the loaders in order) and
+//     `progress[w]` (slices wave w will not read again); a slot is refilled when every wave has let go.
+// Every voxel line of a tile's footprint is read once per tile; neighbouring tiles overlap by the
+// footprint's rim (x: up to one 128-byte cell, y: two rows), which they mostly find in L2.
+//
+// Reference-mode early ray termination (kernel.cu:272-274: one sample per later 30-sample chunk) would
+// keep the stream running for almost nothing, so a wave whose live rays have all terminated leaves the
+// ring and takes those sparse samples by direct gathers like march_kernel.
+#include "vv_device.h"
+#include "vv_kernels.h"
+#include <cmath>
+#include <algorithm>
+
+namespace vv {
+namespace sweepk {
+
+constexpr int kInf = 0x3fffffff;
+constexpr int kTfBytes = 4096;
+constexpr int kCtlBytes = 2048;
+constexpr int kRingOff = kTfBytes + kCtlBytes;
+constexpr int kLdsMax = 160 * 1024;
+constexpr int kMaxChunks = 32;                 // rows (= LDS-DMA pieces) per slice image
+constexpr int kPage = 1024;                    // the ring is handed out in pages
+constexpr int kPages = (kLdsMax - kRingOff) / kPage;
+constexpr int kTab = 32;                       // slices the ring can hold at once (table entries)
+constexpr float kMargin = 0.0625f;             // voxels added around the analytic footprint (float rounding is < 0.01)
+
+typedef int __attribute__((ext_vector_type(4))) i4v;
+typedef int __attribute__((ext_vector_type(2))) i2v;
+struct Ctl {                                   // control block in LDS
+    int landed[4];                             // per loader wave: its rows of the slices k < landed[w] have landed (unused: kInf)
+    int kmin, kmax;                            // slice range of the tile (sweep order)
+    int err, pad_;
+    int progress[16];                          // per consumer wave: slices k < progress[w] are released
+    i2v tab[kTab];                            // per slice k (entry k % kTab): byte address of voxel (x 0, row 0) of its image, row pitch
+    int box[kTab][4];                          // per slice: x0, x1, r0, r1 held (instrumented builds check against it)
+    int owner[kPages + 2];                     // per ring page: the slice whose image occupies it
+    int sink[64];                              // where the prefetch wave's 4-byte loads land
+};
+static_assert(sizeof(Ctl) <= kCtlBytes, "control block");
+
+// Tile frustum in voxel-float coordinates (vb = tex * n - 0.5): eye E and the extreme slopes of the
+// four corner rays against the sweep coordinate.  Every ray of the tile runs inside the hull of the
+// corner rays (directions are affine in the pixel coordinates, ray_endpoints()).
+struct Frustum { float Ex, Er, Es, mx_lo, mx_hi, mr_lo, mr_hi; };
+
+template <int MAJOR>
+__device__ __host__ inline void axis_pick(const float v[3], float &x, float &r, float &s)
+{
+    x = v[0]; r = MAJOR == 2 ? v[1] : v[2]; s = MAJOR == 2 ? v[2] : v[1];
+}
+
+// Footprint of the frustum in slice s: voxel columns x0..x1 and rows r0..r1 (inclusive) that any in-volume
+// sample interpolating with slice s can touch.  Those are the samples whose sweep coordinate zeta lies in
+// [s - 1, s + 1), plus -- slice 1 only, kept for all -- the in-volume samples with zeta in [-0.5, 0), which clamp
+// to slice 0 and read slice 1 with weight 0 (the value must still be finite).  The eye lies outside the slab
+// range (plan_sweep), so (zeta - Es) keeps one sign and each bound is ONE corner slope times a linear function of
+// s: bound(s) = a + m * s, four fused multiply-adds per slice.
+struct Foot { int x0, x1, r0, r1; };
+struct FootLin { float ax_lo, mx_lo, ax_hi, mx_hi, ar_lo, mr_lo, ar_hi, mr_hi; };
+__device__ __host__ inline void foot_linear(const Frustum &F, bool ahead /* zeta - Es > 0 */, FootLin &L)
+{
+    const float c0 = -1.5f, c1 = 1.0f;                 // the slab is [s + c0, s + c1)
+    auto pick = [&](float mlo, float mhi, float E, float &a_lo, float &m_lo, float &a_hi, float &m_hi) {
+        // ahead: min over {mlo, mhi} x {z0, z1} is mlo * (mlo >= 0 ? z0 : z1), max is mhi * (mhi >= 0 ? z1 : z0);
+        // behind (z < 0): min is mhi * (mhi >= 0 ? z0 : z1), max is mlo * (mlo >= 0 ? z1 : z0)
+        m_lo = ahead ? mlo : mhi; m_hi = ahead ? mhi : mlo;
+        const float cl = m_lo >= 0.f ? c0 : c1, ch = m_hi >= 0.f ? c1 : c0;
+        a_lo = E - kMargin + m_lo * (cl - F.Es);
+        a_hi = E + kMargin + m_hi * (ch - F.Es);
+    };
+    pick(F.mx_lo, F.mx_hi, F.Ex, L.ax_lo, L.mx_lo, L.ax_hi, L.mx_hi);
+    pick(F.mr_lo, F.mr_hi, F.Er, L.ar_lo, L.mr_lo, L.ar_hi, L.mr_hi);
+}
+__device__ __forceinline__ Foot footprint(const FootLin &L, int s, int nx, int nr)
+{
+    const float fs = (float)s;
+    const float xlo = __builtin_fmaf(L.mx_lo, fs, L.ax_lo), xhi = __builtin_fmaf(L.mx_hi, fs, L.ax_hi);
+    const float rlo = __builtin_fmaf(L.mr_lo, fs, L.ar_lo), rhi = __builtin_fmaf(L.mr_hi, fs, L.ar_hi);
+    Foot f;
+    f.x0 = (int)fminf(fmaxf(floorf(xlo), 0.f), (float)(nx - 1));
+    f.x1 = (int)fminf(fmaxf(floorf(xhi), 0.f), (float)(nx - 1)) + 1;
+    f.r0 = (int)fminf(fmaxf(floorf(rlo), 0.f), (float)(nr - 1));
+    f.r1 = (int)fminf(fmaxf(floorf(rhi), 0.f), (float)(nr - 1)) + 1;
+    return f;
+}
+
+// minimum over the wave / over each row of 16 lanes by DPP (no LDS traffic)
+template <int CTRL, int ROWMASK> __device__ __forceinline__ int dpp_min(int v)
+{
+    return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ int row16_min(int v)       // lane 15 of every row of 16 holds the row's minimum
+{
+    v = dpp_min<0x111, 0xf>(v); v = dpp_min<0x112, 0xf>(v); v = dpp_min<0x114, 0xf>(v); v = dpp_min<0x118, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ int wave_min_fast(int v)   // uniform result
+{
+    v = row16_min(v);
+    v = dpp_min<0x142, 0xa>(v);                        // row_bcast:15 into rows 1 and 3
+    v = dpp_min<0x143, 0xc>(v);                        // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ bool any_(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ int wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+
+__device__ __forceinline__ int lds_load_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store_i(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Four x-pairs (8 bytes at a 4-byte aligned LDS address each).  hipcc turns such a load into ds_read2_b32; the
+// unaligned ds_read_b64 (experiment build) returns the right bytes but is an order of magnitude slower.
+__device__ __forceinline__ void lds_pairs(const char *a, const char *b, const char *c, const char *d,
+                                          float2u &va, float2u &vb, float2u &vc, float2u &vd)
+{
+#ifndef VV_SWEEP_B64ASM      // measured on MI355X: an unaligned ds_read_b64 costs ~36 cycles per wave instruction (tools/ubench/lds_pairs.hip)
+    va = *(const float2u *)a; vb = *(const float2u *)b; vc = *(const float2u *)c; vd = *(const float2u *)d;
+#else
+    typedef float __attribute__((ext_vector_type(2))) f2;
+    f2 ra, rb, rc, rd;
+    const uint32_t aa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)a, ab = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)b;
+    const uint32_t ac = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)c, ad = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)d;
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(ra), "=&v"(rb), "=&v"(rc), "=&v"(rd) : "v"(aa), "v"(ab), "v"(ac), "v"(ad) : "memory");
+    va = {ra.x, ra.y}; vb = {rb.x, rb.y}; vc = {rc.x, rc.y}; vd = {rd.x, rd.y};
+#endif
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// wait until at most n vector-memory operations of this wave are outstanding (n uniform, 0..kMaxChunks)
+__device__ __forceinline__ void wait_vm_n(int n)
+{
+    n = n > 63 ? 63 : n;                               // the counter has 6 bits; waiting for fewer is only stricter
+    switch (n) {
+#define VV_W(i) case i: wait_vm<i>(); break;
+#define VV_W8(b) VV_W(b) VV_W(b + 1) VV_W(b + 2) VV_W(b + 3) VV_W(b + 4) VV_W(b + 5) VV_W(b + 6) VV_W(b + 7)
+    VV_W8(0) VV_W8(8) VV_W8(16) VV_W8(24) VV_W8(32) VV_W8(40) VV_W8(48) VV_W8(56)
+#undef VV_W8
+#undef VV_W
+    default: wait_vm<0>(); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int MAJOR, bool TEX8, bool GRAY, bool INSTR>
+__global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V,
+                                                     const float4 *__restrict__ tf,
+                                                     const float *__restrict__ rad,
+                                                     uint32_t *__restrict__ pixels,
+                                                     unsigned long long *__restrict__ counter,
+                                                     uint32_t *__restrict__ bricks, SweepArgs S)
+{
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    float *lds_tf = (float *)lds;
+    Ctl *ctl = (Ctl *)(lds + kTfBytes);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long t_start = INSTR ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long t_blk0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // tile of this block.  Raster order dealt to the XCDs by tile row (block L runs on XCD L % 8 under
+    // round-robin dispatch: speed only), or the order the host planned.
+    int trow, tcol;
+    if (S.order) {
+        if ((int)blockIdx.x >= S.n_order) return;
+        const int t = S.order[blockIdx.x];
+        trow = t / S.ntx; tcol = t % S.ntx;
+    } else {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        trow = (j / S.ntx) * 8 + xcd; tcol = j % S.ntx;
+    }
+    if (trow >= S.nty) return;                                        // block-uniform, before any barrier
+    const int tile_w = S.wx * 32, tile_h = S.wy * 2;
+    const int x0 = tcol * tile_w;
+    const int y0 = S.y0 + (trow / S.rows_per_band) * S.band_stride_px + (trow % S.rows_per_band) * tile_h;
+
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        float4 e = tf[i];
+        lds_tf[i] = e.x; lds_tf[256 + i] = e.y; lds_tf[512 + i] = e.z; lds_tf[768 + i] = e.w;
+    }
+    if (threadIdx.x < 16) ctl->progress[threadIdx.x] = kInf;
+    if (threadIdx.x == 16) { ctl->kmin = kInf; ctl->kmax = -1; ctl->err = 0; }
+    if (threadIdx.x >= 32 && threadIdx.x < 36) ctl->landed[threadIdx.x - 32] = (int)threadIdx.x - 32 < S.nl ? 0 : kInf;
+    for (int i = threadIdx.x; i < kPages + 2; i += blockDim.x) ctl->owner[i] = -1;
+    __syncthreads();
+
+    const int nx = V.nx, nr = MAJOR == 2 ? V.ny : V.nz, ns = MAJOR == 2 ? V.nz : V.ny;
+    // slice index s along the sweep axis -> position k in sweep order: s, or ns - s = (s ^ -1) + ns + 1
+    const int kmul = S.sgn > 0 ? 1 : -1, kadd = S.sgn > 0 ? 0 : ns;
+    const int kxor = S.sgn > 0 ? 0 : -1, kxadd = S.sgn > 0 ? 0 : ns + 1;
+
+    if (wave >= S.nc) {
+        // =====================================================================================
+        // loader waves
+        // =====================================================================================
+        const int lw = wave - S.nc;
+        // frustum of the tile from its four corner pixels (pixel centres, ray_endpoints())
+        Frustum F;
+        {
+            float h[3], nn[3] = {(float)V.nx, (float)V.ny, (float)V.nz}, E[3];
+            for (int a = 0; a < 3; ++a) { h[a] = 0.5f * P.inv_scale[a]; E[a] = (P.cam_pos[a] * h[a] + 0.5f) * nn[a] - 0.5f; }
+            axis_pick<MAJOR>(E, F.Ex, F.Er, F.Es);
+            F.mx_lo = F.mr_lo = INFINITY; F.mx_hi = F.mr_hi = -INFINITY;
+            for (int c = 0; c < 4; ++c) {
+                const int px = x0 + ((c & 1) ? tile_w - 1 : 0), py = y0 + ((c & 2) ? tile_h - 1 : 0);
+                const float ndx = (2.0f * ((float)px + 0.5f)) / (float)P.W - 1.0f, ndy = (2.0f * ((float)py + 0.5f)) / (float)P.H - 1.0f;
+                const float sx = ndx * P.tan_half_x, sy = ndy * P.tan_half_y;
+                float D[3];
+                for (int a = 0; a < 3; ++a) D[a] = ((P.side[a] * sx + P.up[a] * sy) + P.look[a]) * h[a] * nn[a];
+                float dx, dr, ds;
+                axis_pick<MAJOR>(D, dx, dr, ds);
+                const float mx = dx / ds, mr = dr / ds;
+                F.mx_lo = fminf(F.mx_lo, mx); F.mx_hi = fmaxf(F.mx_hi, mx);
+                F.mr_lo = fminf(F.mr_lo, mr); F.mr_hi = fmaxf(F.mr_hi, mr);
+            }
+        }
+        FootLin FL;
+        foot_linear(F, S.sgn > 0, FL);
+        // one LDS-DMA piece = one row of the slice's image: lane l copies bytes [16 l, 16 l + 16) of the row
+        // (8 lanes per 128-byte cell; lanes beyond the row's cells are masked)
+        const uint64_t Sr = MAJOR == 2 ? V.row_bytes : V.slice_bytes;       // bytes between rows of the image
+        const uint64_t Ss = MAJOR == 2 ? V.slice_bytes : V.row_bytes;       // bytes between slices
+        __syncthreads();
+        const int kmin = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmin)), kmax = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmax));
+        // the loaders' few instructions must not queue behind the consumers' arithmetic on their SIMD
+        __builtin_amdgcn_s_setprio(3);
+        if (lw >= S.nl) {
+            // ---- prefetch wave (optional): pulls the footprints of the slices ahead of the loaders from HBM into the
+            // XCD's L2, one 4-byte load per 128-byte line into a sink in LDS (no destination register that a late
+            // load could clobber), so that a ring fill lands in a few hundred cycles instead of thousands. ----
+            int kp = kmin, idle = 0;
+            while (kp <= kmax) {
+                const i4v l4 = *(volatile i4v *)ctl->landed;
+                const int ld = __builtin_amdgcn_readfirstlane(min(min(l4.x, l4.y), min(l4.z, l4.w)));
+                if (ld >= kInf) break;
+                if (kp >= ld + S.lead) {
+                    if ((++idle & 15) == 0 && __builtin_amdgcn_readlane(row16_min(lds_load_i(&ctl->progress[lane & 15])), 15) >= kInf) break;
+                    if (idle > (1 << 22)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                idle = 0;
+                const int s = kmul * kp + kadd;
+                Foot f = footprint(FL, s, nx, nr);
+                f.x0 = __builtin_amdgcn_readfirstlane(f.x0); f.x1 = __builtin_amdgcn_readfirstlane(f.x1);
+                f.r0 = __builtin_amdgcn_readfirstlane(f.r0); f.r1 = __builtin_amdgcn_readfirstlane(f.r1);
+                const int c0 = f.x0 >> 5, ncell = min((f.x1 >> 5) - c0 + 1, S.pxc), nrows = min(f.r1 - f.r0 + 1, S.ry);
+                const char *g0 = (const char *)V.data + (uint64_t)s * Ss + (uint64_t)f.r0 * Sr + (uint64_t)c0 * 128u;
+                const int lc = lane & 7, lr = lane >> 3;                 // lane l: line (l % 8) of row (l / 8), 8 rows per instruction
+                if (lc < ncell) {
+                    for (int r0 = 0; r0 < nrows; r0 += 8) {
+                        if (r0 + lr < nrows) {
+                            const char *g = g0 + (uint64_t)(r0 + lr) * Sr + (uint32_t)lc * 128u;
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                             (__attribute__((address_space(3))) void *)ctl->sink, 4, 0, 0);
+                        }
+                    }
+                }
+                ++kp;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        // ---- loader wave lw: rows lw, lw + nl, ... of every slice's image.  The ring is handed out in 1 KiB pages, in
+        // slice order, as a circular first-in-first-out buffer: slice k takes ceil(rows * pitch / 1 KiB) pages at `head`,
+        // or at page 0 when they do not fit before the end.  Every loader wave derives the same positions from the same
+        // footprints, so the waves never talk to each other; a slice is complete when all of them have landed their rows
+        // (consumers take the minimum of landed[]).  A page may be overwritten once the slice that owns it is released by
+        // every consumer wave. ----
+        if (lane == 0) lds_store_i(&ctl->landed[lw], kmin);             // slices before kmin are never asked for
+        int kn = kmin, kq = kmin;            // next slice to issue; oldest slice issued and not yet confirmed
+        int head = 0, pend = 0, outstanding = 0, idle = 0;
+        unsigned long long qn = 0, qk = 0;   // LDS-DMA instructions and slices of the pending groups, 8 bits each, oldest lowest
+        bool bail = false;
+        unsigned long long t_issue = 0, t_land = 0, t_pub = 0, t_idle = 0, tt = 0;
+        const unsigned long long t_pro = INSTR ? __builtin_readcyclecounter() - t_start : 0ull;
+        for (;;) {
+            if (INSTR) tt = __builtin_readcyclecounter();
+            // ---- 1. issue the next group of up to `group` slices if the ring has room for it.  A group shares one
+            //         footprint (the union over its slices), one allocation and one confirmation: the per-slice cost of
+            //         the loaders' bookkeeping would otherwise exceed the time the copies themselves take. ----
+            bool issued_now = false;
+            if (kn <= kmax && pend < S.depth) {
+                const int pr = max(__builtin_amdgcn_readlane(row16_min(lds_load_i(&ctl->progress[lane & 15])), 15), kmin);
+                if (pr >= kInf) { bail = true; break; }                 // every consumer wave has left the ring
+                const int ke = min(kn + S.group - 1, kmax), ng = ke - kn + 1;
+                const int sa = kmul * kn + kadd, sb = kmul * ke + kadd;
+                const Foot fa = footprint(FL, sa, nx, nr), fb = footprint(FL, sb, nx, nr);
+                Foot f;
+                f.x0 = __builtin_amdgcn_readfirstlane(min(fa.x0, fb.x0)); f.x1 = __builtin_amdgcn_readfirstlane(max(fa.x1, fb.x1));      // uniform by construction:
+                f.r0 = __builtin_amdgcn_readfirstlane(min(fa.r0, fb.r0)); f.r1 = __builtin_amdgcn_readfirstlane(max(fa.r1, fb.r1));      // scalar loops and branches
+                const int c0 = f.x0 >> 5;
+                int ncell = (f.x1 >> 5) - c0 + 1, nrows = f.r1 - f.r0 + 1;
+                if (ncell > S.pxc || nrows > S.ry) { if (lane == 0) lds_store_i(&ctl->err, 2); ncell = min(ncell, S.pxc); nrows = min(nrows, S.ry); }
+                const int pitch = ncell * 128, img_bytes = nrows * pitch;
+                const int np = (ng * img_bytes + kPage - 1) / kPage;
+                const int pos = head + np <= kPages ? head : 0;
+                const int n_my = ng * ((nrows - lw + S.nl - 1) / S.nl);
+                bool ok = ke - pr < kTab && (pend == 0 || outstanding + n_my <= 60);
+                if (ok) {
+                    bool busy = false;
+                    for (int b0 = 0; b0 < np; b0 += 64) {
+                        if (b0 + lane < np) { const int o = lds_load_i(&ctl->owner[pos + b0 + lane]); busy = busy || !(o < pr || o == ke); }
+                    }
+                    ok = !any_(busy);
+                }
+                if (ok) {
+                    for (int b0 = 0; b0 < np; b0 += 64)
+                        if (b0 + lane < np) lds_store_i(&ctl->owner[pos + b0 + lane], ke);
+                    const int img = kRingOff + pos * kPage;
+                    if (lane < ng) {
+                        *(volatile i2v *)&ctl->tab[(kn + lane) & (kTab - 1)] = i2v{img + lane * img_bytes - f.r0 * pitch - c0 * 128, pitch};
+                        if (INSTR) { int *bx = ctl->box[(kn + lane) & (kTab - 1)]; bx[0] = c0 * 32; bx[1] = (c0 + ncell) * 32 - 1; bx[2] = f.r0; bx[3] = f.r0 + nrows - 1; }
+                    }
+                    const char *gs = (const char *)V.data + (int64_t)sa * (int64_t)Ss + ((uint64_t)f.r0 + lw) * Sr + (uint64_t)c0 * 128u + (uint32_t)lane * 16u;
+                    const int64_t gstep = (int64_t)kmul * (int64_t)Ss;
+                    int ls = img + lw * pitch;
+                    const bool mine = lane < 8 * ncell;
+#pragma unroll 1
+                    for (int j = 0; j < ng; ++j) {
+                        const char *gp = gs;
+                        int lb = ls;
+#pragma unroll 1
+                        for (int rr = lw; rr < nrows; rr += S.nl) {
+                            if (mine)
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                                                 (__attribute__((address_space(3))) void *)(lds + lb), 16, 0, 0);
+                            gp += Sr * S.nl; lb += pitch * S.nl;
+                        }
+                        gs += gstep; ls += img_bytes;
+                    }
+                    qn |= (unsigned long long)n_my << (8 * pend);
+                    qk |= (unsigned long long)ng << (8 * pend);
+                    ++pend; outstanding += n_my; head = pos + np; kn = ke + 1;
+                    issued_now = true; idle = 0;
+                    if (INSTR && lane == 0 && lw == 0) atomicAdd(counter + 5, (unsigned long long)ng * nrows * ncell * 128ull);
+                    if (INSTR) t_issue += __builtin_readcyclecounter() - tt;
+                }
+            }
+            // ---- 2. confirm the oldest pending slice: when `depth` slices are pending, or nothing could be issued.  Its rows have
+            //         landed once only the younger slices' instructions are outstanding (vmcnt retires in issue order). ----
+            if (pend > 0 && (pend >= S.depth || !issued_now)) {
+                const int n0 = (int)(qn & 255ull);
+                wait_vm_n(outstanding - n0);
+                kq += (int)(qk & 255ull);
+                if (lane == 0) lds_store_i(&ctl->landed[lw], kq);
+                qn >>= 8; qk >>= 8; --pend; outstanding -= n0; idle = 0;
+                if (INSTR) t_land += __builtin_readcyclecounter() - tt;
+                continue;
+            }
+            if (issued_now) continue;
+            if (kn > kmax) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (INSTR) t_idle += __builtin_readcyclecounter() - tt;
+            if (++idle > (1 << 22)) { if (lane == 0) lds_store_i(&ctl->err, 1); bail = true; break; }
+        }
+        wait_vm<0>();                     // nothing of this wave may land in LDS after it has gone
+        // open the gate for good: a consumer that asked for more than kmax would otherwise wait forever (it cannot,
+        // but a wrong pixel beats a hung GPU)
+        if (lane == 0) lds_store_i(&ctl->landed[lw], kInf);
+        if (INSTR && lane == 0) {
+            atomicAdd(counter + 8, t_issue); atomicAdd(counter + 9, t_land); atomicAdd(counter + 10, t_pub); atomicAdd(counter + 11, t_idle);
+            atomicAdd(counter + 12, t_pro);
+        }
+        (void)bail;
+        return;
+    }
+
+    // =========================================================================================
+    // consumer waves: 32 x 2 pixels each, wx x wy of them tile the block's tile_w x tile_h pixels
+    // =========================================================================================
+    const int x = x0 + (wave % S.wx) * 32 + (lane & 31), y = y0 + (wave / S.wx) * 2 + (lane >> 5);
+    const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax = P.H >= 2 ? P.H - 2 : 0;
+    const bool in_frame = x <= xmax && y <= ymax && row_owned(P, y);
+
+    float res_r = 0.f, res_g = 0.f, res_b = 0.f, res_a = 0.f;
+    unsigned long long executed = 0, slots = 0, misses = 0, stalls = 0;
+    bool write_zero = false;
+    Ray r;
+    bool alive = false;
+    if (in_frame) {
+        f3 front, back;
+        ray_endpoints(P, x, y, front, back);
+        float length = vlen3(back.x - front.x, back.y - front.y, back.z - front.z);
+        if (length < 0.001f) {
+            write_zero = true;                                           // kernel.cu:334-338
+        } else {
+            float rd;
+            if (P.W < 2 || P.H < 2) rd = vlen3(front.x - P.cam_pos[0], front.y - P.cam_pos[1], front.z - P.cam_pos[2]);
+            else rd = rad[owner_slab(y, P.H, P.nby, P.conflict_y) * P.nbx + owner_slab(x, P.W, P.nbx, P.conflict_x)];
+            setup_ray(P, front, back, rd, r);
+            alive = !r.cut_return;
+        }
+    }
+    if (!alive) { r.upper = -1.f; r.dist0 = 0.f; r.sstep = 1.f; r.origin = mk3(0, 0, 0); r.dir = r.origin; r.sdir = r.origin; }
+
+    // slices this ray can touch, with a margin: positions at both ends of [dist0, upper]
+    {
+        int klo = kInf, khi = -1;
+        if (alive && r.dist0 < r.upper) {
+            const float os = MAJOR == 2 ? r.origin.z : r.origin.y, dsv = MAJOR == 2 ? r.dir.z : r.dir.y;
+            const float isc = MAJOR == 2 ? P.inv_scale[2] : P.inv_scale[1];
+            const float ta = __builtin_fmaf((os + dsv * r.dist0) - 0.5f, isc, 0.5f), tb = __builtin_fmaf((os + dsv * r.upper) - 0.5f, isc, 0.5f);
+            const float za = ta * (float)ns - 0.5f, zb = tb * (float)ns - 0.5f;
+            const int slo = (int)fminf(fmaxf(floorf(fminf(za, zb) - 1.5f), 0.f), (float)(ns - 1));
+            const int shi = (int)fminf(fmaxf(floorf(fmaxf(za, zb) + 1.5f), 0.f), (float)(ns - 1)) + 1;
+            klo = S.sgn > 0 ? slo : ns - shi; khi = S.sgn > 0 ? shi : ns - slo;
+        }
+        klo = wave_min_i(klo); khi = wave_max_i(khi);
+        if (lane == 0 && khi >= 0) { atomicMin(&ctl->kmin, klo); atomicMax(&ctl->kmax, khi); lds_store_i(&ctl->progress[wave], 0); }
+    }
+    __syncthreads();
+    const int kmin = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmin));
+
+    float dist = r.dist0;
+    int i = 0, n = 0, chunks = 0;             // next sample of the open chunk (0: the lane has to open a chunk), samples in it
+    float px = 0.f, py = 0.f, pz = 0.f;
+    bool ert = false;
+    int tail = 0;                             // wave-uniform: the wave has left the ring (its live rays have all terminated early)
+    int pw = 0;                               // published progress of this wave
+    int kl = kmin;                            // slices k < kl have landed
+    int stall_run = 0;
+    const int needoff = S.sgn > 0 ? 1 : 0;
+    unsigned long long t_stall = 0, t_c0 = __builtin_readcyclecounter(), t_s = 0;
+    const unsigned long long t_loop0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long t_r0 = INSTR ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
+
+    for (;;) {
+        if (INSTR) t_s = __builtin_readcyclecounter();
+        // ---- open the next 30-sample chunk (kernel.cu:248-257): its sample count by the reference's own predicate ----
+        if (any_(alive && i == 0)) {
+            if (alive && i == 0) {
+#pragma clang fp contract(off)
+                if (!(dist < r.upper) || chunks >= P.max_chunks) alive = false;
+                else {
+                    n = chunk_count(dist, r.upper, r.sstep);
+                    if (ert) n = min(n, 1);                              // DESIGN.md pin 4: later chunks composite one sample
+                    ++chunks;
+                    if (n == 0) dist += r.sstep * kChunkSteps;           // the inner loop breaks at i == 1 (kernel.cu:255-257)
+                    else { px = r.origin.x + r.dir.x * dist; py = r.origin.y + r.dir.y * dist; pz = r.origin.z + r.dir.z * dist; i = 1; }
+                }
+            }
+        }
+        if (!any_(alive)) break;
+        if (!tail && !any_(alive && !ert)) {
+            tail = 1;
+            if (lane == 0) lds_store_i(&ctl->progress[wave], kInf);
+        }
+        tail = __builtin_amdgcn_readfirstlane(tail);
+        if (!tail) { const i4v l4 = *(volatile i4v *)ctl->landed; kl = min(min(l4.x, l4.y), min(l4.z, l4.w)); }
+        asm volatile("" ::: "memory");        // the flag is read before any slice data of this step
+
+        // ---- candidate: sample i of the open chunk (kernel.cu:136-141) ----
+        const float qx = px + r.sdir.x, qy = py + r.sdir.y, qz = pz + r.sdir.z;
+        const float tx = __builtin_fmaf(qx - 0.5f, P.inv_scale[0], 0.5f);
+        const float ty = __builtin_fmaf(qy - 0.5f, P.inv_scale[1], 0.5f);
+        const float tz = __builtin_fmaf(qz - 0.5f, P.inv_scale[2], 0.5f);
+        uint32_t ix, iy, iz;
+        const float wx = axis_coord<TEX8>(tx, (float)V.nx, (float)(V.nx - 1), ix);
+        const float wy = axis_coord<TEX8>(ty, (float)V.ny, (float)(V.ny - 1), iy);
+        const float wz = axis_coord<TEX8>(tz, (float)V.nz, (float)(V.nz - 1), iz);
+        const int is = (int)(MAJOR == 2 ? iz : iy), ir = (int)(MAJOR == 2 ? iy : iz);
+        const int k0 = (is ^ kxor) + kxadd;              // position of slice `is`; slice is + 1 sits at k0 + kmul
+        const int need = k0 + needoff;                   // the later of the two
+        // ---- release slices no lane of this wave will read again: a ray's positions only grow, so the earlier slice of
+        //      its candidate bounds everything it will still read.  Done before the wave may stall: a wave that waits
+        //      for slices far ahead must not hold the ring back (its published progress gates the loaders) ----
+        if (!tail) {
+            const int fr = need - 1;
+            if (!any_(alive && fr <= pw)) {
+                const int m = wave_min_fast(alive ? fr : kInf);
+                if (m < kInf && m > pw) {
+                    pw = m;
+                    if (lane == 0) lds_store_i(&ctl->progress[wave], pw);
+                }
+            }
+        }
+        const bool open = alive && i != 0;
+        const bool take = open && (tail != 0 || need < kl);
+        if (!any_(take)) {
+            if (any_(alive && i == 0)) continue;         // an empty chunk: open the next one
+            // nothing to do until the loaders catch up
+            if (INSTR) ++stalls;
+            __builtin_amdgcn_s_sleep(1);
+            if (INSTR) t_stall += __builtin_readcyclecounter() - t_s;
+            if (++stall_run > (1 << 21)) {               // watchdog: a wrong pixel beats a hung GPU
+#ifdef VV_SWEEP_DEBUG
+                {
+                    const int mn = wave_min_fast(open ? need : kInf);
+                    if (lane == 0) printf("watchdog tile (%d,%d) wave %d: kl %d loaded %d min need %d pw %d kmin %d kmax %d progress %d %d %d %d %d %d %d %d %d %d %d %d\n", tcol, trow, wave, kl,
+                        lds_load_i(&ctl->landed[0]), mn, pw, kmin, lds_load_i(&ctl->kmax), ctl->progress[0], ctl->progress[1], ctl->progress[2], ctl->progress[3], ctl->progress[4], ctl->progress[5],
+                        ctl->progress[6], ctl->progress[7], ctl->progress[8], ctl->progress[9], ctl->progress[10], ctl->progress[11]);
+                }
+#endif
+                if (lane == 0) { lds_store_i(&ctl->err, 3); lds_store_i(&ctl->progress[wave], kInf); }
+                alive = false;
+            }
+            continue;
+        }
+        stall_run = 0;
+        if (INSTR) slots += 64;
+
+        // ---- eight corners ----
+        uint32_t idx;
+        if (!tail) {
+            const i2v T0 = *(volatile i2v *)&ctl->tab[k0 & (kTab - 1)], T1 = *(volatile i2v *)&ctl->tab[(k0 + kmul) & (kTab - 1)];
+            const int x4 = (int)(ix << 2);
+            const char *p0 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)T0.y) + (T0.x + x4));
+            const char *p1 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)T1.y) + (T1.x + x4));
+            float2u c00, c10, c01, c11;
+            lds_pairs(p0, p0 + T0.y, p1, p1 + T1.y, c00, c10, c01, c11);
+            // MAJOR == 2: rows are y, slices z.  MAJOR == 1: rows are z, slices y -- the lerp order stays x, y, z
+            const float2u a_ = c00, b_ = MAJOR == 2 ? c10 : c01, c_ = MAJOR == 2 ? c01 : c10, d_ = c11;
+            const float e00 = __builtin_fmaf(wx, a_.y - a_.x, a_.x);      // (y, z)
+            const float e10 = __builtin_fmaf(wx, b_.y - b_.x, b_.x);      // (y+1, z)
+            const float e01 = __builtin_fmaf(wx, c_.y - c_.x, c_.x);      // (y, z+1)
+            const float e11 = __builtin_fmaf(wx, d_.y - d_.x, d_.x);
+            const float f0 = __builtin_fmaf(wy, e10 - e00, e00);
+            const float f1 = __builtin_fmaf(wy, e11 - e01, e01);
+            const float L = __builtin_fmaf(wz, f1 - f0, f0);
+            idx = min((uint32_t)(L * 255.0f), 255u);
+            idx = bounds_check(tx, ty, tz) ? idx : 0u;
+            if (INSTR && take && bounds_check(tx, ty, tz)) {
+                const int *bx0 = ctl->box[k0 & (kTab - 1)], *bx1 = ctl->box[(k0 + kmul) & (kTab - 1)];
+                const bool ok = (int)ix >= bx0[0] && (int)ix + 1 <= bx0[1] && ir >= bx0[2] && ir + 1 <= bx0[3] &&
+                                (int)ix >= bx1[0] && (int)ix + 1 <= bx1[1] && ir >= bx1[2] && ir + 1 <= bx1[3];
+                if (!ok) ++misses;
+            }
+        } else {
+            idx = V.big ? sample_index<VV_VOXEL_F32, TEX8, true>(V, tx, ty, tz) : sample_index<VV_VOXEL_F32, TEX8, false>(V, tx, ty, tz);
+        }
+        float cr, cg, cb, ca;
+        ca = lds_tf[768 + idx];
+        cr = lds_tf[idx];
+        if (GRAY) { cg = cb = cr; }
+        else { cg = lds_tf[256 + idx]; cb = lds_tf[512 + idx]; }
+        if (INSTR && take) {
+            executed++;
+            if (bricks && bounds_check(tx, ty, tz)) mark_bricks(bricks, V, tx, ty, tz);
+        }
+        {
+            // :268-270 + blend :107-118, predicated (the table is finite)
+#pragma clang fp contract(off)
+            const float bf = (take && ca > kEps) ? ca * (1.f - res_a) : 0.f;
+            res_r = res_r + cr * bf;
+            if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
+            res_a = res_a + bf;
+        }
+        const bool hit = take && res_a > P.ert_thr;                      // :272-274
+        ert = ert || hit;
+        if (take) { px = qx; py = qy; pz = qz; ++i; }
+        // the chunk ends after its last sample, or -- the ray terminating early -- after this one
+        if (take && (i > n || hit)) {
+#pragma clang fp contract(off)
+            dist += r.sstep * kChunkSteps;                               // :277
+            i = 0;
+            if (P.ert_true && ert) alive = false;
+        }
+    }
+    if (!tail && lane == 0) lds_store_i(&ctl->progress[wave], kInf);
+    if (S.trace && wave == 0 && lane == 0) {
+        unsigned long long *t = S.trace + 8ull * blockIdx.x;
+        t[0] = t_blk0; t[1] = t_loop0; t[2] = __builtin_amdgcn_s_memrealtime();
+        t[3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63508);
+        t[4] = ((unsigned long long)trow << 32) | (unsigned)tcol; t[5] = ((unsigned long long)(unsigned)lds_load_i(&ctl->kmax) << 32) | (unsigned)kmin; t[6] = (unsigned long long)chunks; t[7] = 1;
+    }
+
+    if (in_frame) {
+        if (GRAY) { res_g = res_r; res_b = res_r; }
+        pixels[(size_t)y * P.W + x] = write_zero ? 0u : pack_rgba(res_r, res_g, res_b, res_a);
+    }
+    if (INSTR) {
+        for (int o = 32; o > 0; o >>= 1) { executed += __shfl_down(executed, o); misses += __shfl_down(misses, o); }
+        if (lane == 0 && executed) atomicAdd(counter, executed);
+        if (lane == 0 && slots) atomicAdd(counter + 1, slots);
+        if (lane == 0 && misses) atomicAdd(counter + 4, misses);
+        if (lane == 0 && stalls) atomicAdd(counter + 6, stalls);
+        if (lane == 0) { atomicAdd(counter + 13, __builtin_readcyclecounter() - t_c0); atomicAdd(counter + 14, t_stall); atomicAdd(counter + 15, __builtin_amdgcn_s_memrealtime() - t_r0); }
+        if (lane == 0 && wave == 0) { const int e = lds_load_i(&ctl->err); if (e) atomicAdd(counter + 7, 1ull << (16 * (e - 1))); }   // four 16-bit counts: codes 1..4
+    }
+}
+
+template <int MAJOR, bool TEX8, bool GRAY, bool INSTR>
+static void launch_one(const MarchArgs &a, hipStream_t s)
+{
+    const SweepArgs &S = a.sweep;
+    const unsigned nblocks = S.order ? (unsigned)S.n_order : (unsigned)(((S.nty + 7) / 8) * 8 * S.ntx);
+    auto kern = sweep_kernel<MAJOR, TEX8, GRAY, INSTR>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3((unsigned)((S.nc + S.nl + (S.lead > 0 ? 1 : 0)) * 64)), (size_t)S.lds_bytes, s,
+                       a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, S);
+}
+template <int MAJOR>
+static void launch_major(const MarchArgs &a, hipStream_t s)
+{
+    const bool gray = a.gray;
+    if (a.tex8) {
+        if (gray) { if (a.instr) launch_one<MAJOR, true, true, true>(a, s); else launch_one<MAJOR, true, true, false>(a, s); }
+        else      { if (a.instr) launch_one<MAJOR, true, false, true>(a, s); else launch_one<MAJOR, true, false, false>(a, s); }
+    } else {
+        if (gray) { if (a.instr) launch_one<MAJOR, false, true, true>(a, s); else launch_one<MAJOR, false, true, false>(a, s); }
+        else      { if (a.instr) launch_one<MAJOR, false, false, true>(a, s); else launch_one<MAJOR, false, false, false>(a, s); }
+    }
+}
+
+} // namespace sweepk
+
+void launch_raymarch_sweep(const MarchArgs &a, hipStream_t s)
+{
+    if (a.sweep.major == 2) sweepk::launch_major<2>(a, s); else sweepk::launch_major<1>(a, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side plan: does the frame qualify, along which axis, and how large must the LDS image of a
+// slice be.  Mirrors the device's footprint() in double precision with slack, so the device never
+// finds a footprint larger than the slot (it would flag err = 2 in instrumented runs).
+// ---------------------------------------------------------------------------------------------
+void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
+{
+    using namespace sweepk;
+    SweepArgs &S = A.sweep;
+    S.enabled = 0;
+    const FrameParams &P = A.P;
+    const VolumeView &V = A.V;
+    if (A.phong || A.V_type != VV_VOXEL_F32 || P.slice_type != SLICE_NONE) return;
+    if (P.ray_mode != VV_RAYS_ANALYTIC || P.quantize8) return;
+    if ((V.row_bytes & 15u) || (V.slice_bytes & 15u) || ((uintptr_t)V.data & 15u)) return;
+    if (!(P.step[0] == P.step[1] && P.step[1] == P.step[2])) return;      // samples of a chunk must stay on the ray's line
+    if (P.W < 2 || P.H < 2 || n_rows_px < 1) return;
+    const double n[3] = {(double)V.nx, (double)V.ny, (double)V.nz};
+    double h[3], E[3];
+    bool outside = false;
+    for (int a = 0; a < 3; ++a) {
+        h[a] = 0.5 * (double)P.inv_scale[a];
+        E[a] = ((double)P.cam_pos[a] * h[a] + 0.5) * n[a] - 0.5;
+        if (fabs((double)P.cam_pos[a]) > (double)P.scale[a] * 1.0001) outside = true;
+    }
+    if (!outside) return;                                                 // eye inside the cube: front = (0,0,0) rays (kernel.cu:317-321 quirk)
+    auto dirD = [&](double px, double py, double D[3]) {
+        const double sx = ((2.0 * (px + 0.5)) / P.W - 1.0) * P.tan_half_x, sy = ((2.0 * (py + 0.5)) / P.H - 1.0) * P.tan_half_y;
+        for (int a = 0; a < 3; ++a) D[a] = (P.side[a] * sx + P.up[a] * sy + P.look[a]) * h[a] * n[a];
+    };
+    // sweep axis: y or z, the one every ray of the frame crosses most steeply, all in the same direction
+    int best = 0, best_sgn = 0; double best_q = 0.0;
+    for (int ax = 1; ax <= 2; ++ax) {
+        double lo = INFINITY, hi = -INFINITY, q = INFINITY;
+        for (int c = 0; c < 4; ++c) {
+            double D[3]; dirD((c & 1) ? P.W - 1 : 0, (c & 2) ? P.H - 1 : 0, D);
+            const double len = sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
+            lo = std::min(lo, D[ax]); hi = std::max(hi, D[ax]); q = std::min(q, fabs(D[ax]) / len);
+        }
+        if (lo * hi <= 0.0) continue;                                     // rays cross these planes both ways
+        // the eye must sit before the first slice (every in-volume point has (zeta - Es) of one sign)
+        if (lo > 0.0 ? !(E[ax] < -1.5) : !(E[ax] > n[ax] + 1.5)) continue;
+        if (q > best_q) { best_q = q; best = ax; best_sgn = lo > 0.0 ? 1 : -1; }
+    }
+    if (!best || best_q < 0.35) return;
+    // sample spacing along the sweep axis, in slices: beyond ~3 whole slices would be streamed for nothing
+    {
+        const double dz = (double)P.step[best] * (double)P.inv_scale[best] * n[best];
+        if (!(dz <= 3.0)) return;
+    }
+    const int xa = 0, ra = best == 2 ? 1 : 2, sa = best;
+    const int nr = (int)n[ra], ns = (int)n[sa];
+    S.major = best; S.sgn = best_sgn;
+    // tile shape: wx x wy waves of 32 x 2 pixels.  Wide and short, so that a slice's image has few, long rows
+    // (one LDS-DMA instruction per row) and the rim the neighbours re-read is small.
+    S.nl = 2; S.wx = 3; S.wy = 4;
+    if (const char *e = getenv("VV_SWEEP_NL")) { int t = atoi(e); if (t >= 1 && t <= 4) S.nl = t; }
+    if (const char *e = getenv("VV_SWEEP_WX")) { int t = atoi(e); if (t >= 1 && t <= 8) S.wx = t; }
+    if (const char *e = getenv("VV_SWEEP_WY")) { int t = atoi(e); if (t >= 1 && t <= 14) S.wy = t; }
+    S.group = 4;                             // slices per allocation / confirmation unit of the loaders
+    if (const char *e = getenv("VV_SWEEP_GROUP")) { int t = atoi(e); if (t >= 1 && t <= 8) S.group = t; }
+    S.depth = 2;                             // groups a loader wave keeps pending before it waits for the oldest
+    if (const char *e = getenv("VV_SWEEP_DEPTH")) { int t = atoi(e); if (t >= 1 && t <= 8) S.depth = t; }
+    S.lead = 0;                              // slices the prefetch wave runs ahead of the landed ones (0: no prefetch wave)
+    if (const char *e = getenv("VV_SWEEP_LEAD")) { int t = atoi(e); if (t >= 0 && t <= 64) S.lead = t; }
+    if (S.wx * S.wy + S.nl + (S.lead > 0 ? 1 : 0) > 16) return;
+    const bool forced = getenv("VV_SWEEP_WX") || getenv("VV_SWEEP_WY");
+    for (;;) {
+        S.nc = S.wx * S.wy;
+        const int tw = 32 * S.wx, th = 2 * S.wy;
+        S.ntx = (P.W + tw - 1) / tw;
+        if (P.count > 1) {
+            S.rows_per_band = (P.band * kSlab + th - 1) / th; S.band_stride_px = P.count * P.band * kSlab;
+            S.nty = own_bands * S.rows_per_band;
+        } else { S.rows_per_band = 1 << 28; S.band_stride_px = 0; S.nty = (n_rows_px + th - 1) / th; }
+        S.y0 = y_first;
+        // largest footprint over the tiles that can meet the volume, at both ends of the sweep
+        double ext_x = 0.0, ext_r = 0.0;
+        for (int t = 0; t < S.nty; ++t) {
+            const int py0 = S.y0 + (t / S.rows_per_band) * S.band_stride_px + (t % S.rows_per_band) * th;
+            for (int tc = 0; tc < S.ntx; ++tc) {
+                double mxl = INFINITY, mxh = -INFINITY, mrl = INFINITY, mrh = -INFINITY;
+                for (int c = 0; c < 4; ++c) {
+                    double D[3]; dirD(tc * tw + ((c & 1) ? tw - 1 : 0), py0 + ((c & 2) ? th - 1 : 0), D);
+                    const double mx = D[xa] / D[sa], mr = D[ra] / D[sa];
+                    mxl = std::min(mxl, mx); mxh = std::max(mxh, mx); mrl = std::min(mrl, mr); mrh = std::max(mrh, mr);
+                }
+                double hx_lo = INFINITY, hx_hi = -INFINITY, hr_lo = INFINITY, hr_hi = -INFINITY, ex = 0.0, er = 0.0;
+                for (int end = 0; end < 2; ++end) {
+                    const double sl = end ? ns : 0;
+                    const double z0 = sl - 1.5 - (S.group - 1) - E[sa], z1 = sl + 1.0 + (S.group - 1) - E[sa];   // a group's slab, whichever way it extends
+                    const double xs[4] = {mxl * z0, mxl * z1, mxh * z0, mxh * z1}, rs[4] = {mrl * z0, mrl * z1, mrh * z0, mrh * z1};
+                    const double xl = *std::min_element(xs, xs + 4), xh = *std::max_element(xs, xs + 4);
+                    const double rl = *std::min_element(rs, rs + 4), rh = *std::max_element(rs, rs + 4);
+                    ex = std::max(ex, xh - xl); er = std::max(er, rh - rl);
+                    hx_lo = std::min(hx_lo, E[xa] + xl); hx_hi = std::max(hx_hi, E[xa] + xh);
+                    hr_lo = std::min(hr_lo, E[ra] + rl); hr_hi = std::max(hr_hi, E[ra] + rh);
+                }
+                if (hx_hi < -2.0 || hx_lo > n[xa] + 1.0 || hr_hi < -2.0 || hr_lo > n[ra] + 1.0) continue;   // the tile's frustum misses the volume
+                ext_x = std::max(ext_x, ex); ext_r = std::max(ext_r, er);
+            }
+        }
+        const double slack = 2.0 * kMargin + 0.01;
+        S.pxc = (int)floor((ext_x + slack + 2.0) / 32.0) + 2;
+        S.ry = (int)floor(ext_r + slack) + 3;
+        S.pxc = std::min(S.pxc, (V.nx + 31) / 32 + 1);
+        S.ry = std::min(S.ry, nr + 1);
+        S.slot_bytes = S.pxc * 128 * S.ry;                               // the largest image of a slice
+        S.ring = (kPages * kPage) / S.slot_bytes;                        // slices of that size the ring holds (it holds more of the smaller ones)
+        if (S.pxc <= 8 && S.ry <= kMaxChunks && S.ring >= 5) break;
+        // footprint too large for the LDS (sparse pixels): smaller tiles, else no sweep
+        if (forced) return;
+        if (S.wy > 2) S.wy -= 1; else if (S.wx > 1) { S.wx -= 1; S.wy = 4; } else return;
+    }
+    (void)nr;
+    S.lds_bytes = kRingOff + kPages * kPage;
+    S.order = nullptr; S.n_order = 0; S.trace = nullptr;
+    S.enabled = 1;
+}
+
+} // namespace vv

@@ -68,7 +68,7 @@ EXPORTS = [
     "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid", "vv_debug_counters",
     "vv_first_pass", "vv_cut_plane_canonical", "vv_cut_plane_to_slice_params", "vv_slice_to_bgra",
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
-    "vv_prepare_layouts", "vv_device_bytes",
+    "vv_prepare_layouts", "vv_device_bytes", "vv_debug_sweep_trace",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
 ]
 
@@ -123,6 +123,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_cut_plane_from_drag.argtypes = [vp, vp, vp, f, vp, vp, vp, vp, vp, vp]
     lib.vv_cut_plane_drag.argtypes = [vp, vp, vp, i, i, i, i]
     lib.vv_debug_counters.argtypes = [vp, vp]
+    lib.vv_debug_sweep_trace.argtypes = [vp, vp, i]
     lib.vv_prepare_layouts.argtypes = [vp, i, vp]
     lib.vv_device_bytes.argtypes = [vp, vp]
     lib.vv_volume_dims.argtypes = [vp, C.POINTER(i * 3), C.POINTER(i)]
@@ -331,9 +332,16 @@ class Context:
         return float(self.lib.vv_last_frame_ms(self.h))
 
     def debug_counters(self):
-        out = np.zeros(8, np.uint64)
+        out = np.zeros(16, np.uint64)
         self._chk(self.lib.vv_debug_counters(self.h, out.ctypes.data))
         return out
+
+    def sweep_trace(self, max_blocks: int = 65536):
+        out = np.zeros((max_blocks, 8), np.uint64)
+        n = self.lib.vv_debug_sweep_trace(self.h, out.ctypes.data, max_blocks)
+        if n < 0:
+            raise VolvizError(n, "no sweep trace (render with VV_SWEEP_TRACE=1)")
+        return out[:n]
 
     def last_sample_count(self) -> int:
         return int(self.lib.vv_last_sample_count(self.h))
