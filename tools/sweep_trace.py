@@ -21,7 +21,8 @@ t0 = t[:, 0].min()
 start, loop, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0     # microseconds
 hw, xcc = (t[:, 3] >> np.uint64(32)).astype(np.int64), (t[:, 3] & np.uint64(0xffffffff)).astype(np.int64)
 cu = ((xcc & 15) << 12) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 7) | ((hw >> 8) & 15)           # xcc, se, sh, cu
-work = (t[:, 5] >> np.uint64(32)).astype(np.int64) >= (t[:, 5] & np.uint64(0xffffffff)).astype(np.int64)
+kmx = (t[:, 5] >> np.uint64(32)).astype(np.uint32).astype(np.int32).astype(np.int64); kmn = (t[:, 5] & np.uint64(0xffffffff)).astype(np.uint32).astype(np.int32).astype(np.int64)
+work = kmx >= kmn
 print("blocks", len(t), "with work", int(work.sum()), "distinct CUs", len(np.unique(cu)))
 dur = end - start
 print("span of the kernel (us)", end.max())
@@ -32,7 +33,9 @@ for c, d, w_ in zip(cu, dur, work):
     busy.setdefault(c, [0.0, 0]); busy[c][0] += d; busy[c][1] += int(w_)
 b = np.array([v[0] for v in busy.values()]); k = np.array([v[1] for v in busy.values()])
 print("per CU: busy us mean %.1f min %.1f max %.1f ; working tiles per CU mean %.2f min %d max %d" % (b.mean(), b.min(), b.max(), k.mean(), k.min(), k.max()))
-sl = ((t[:, 5] >> np.uint64(32)).astype(np.int64) - (t[:, 5] & np.uint64(0xffffffff)).astype(np.int64) + 1)[work]
+sl = (kmx - kmn + 1)[work]
+it = (t[:, 6] & np.uint64(0xffffffff)).astype(np.int64)[work]; st = (t[:, 6] >> np.uint64(32)).astype(np.int64)[work]
+print("wave 0 of working tiles: steps mean %.0f, stall iterations mean %.0f; us per step %.3f" % (it.mean(), st.mean(), (dur[work] / np.maximum(it, 1)).mean()))
 print("slices per working tile mean %.0f ; us per slice %.3f" % (sl.mean(), (dur[work] / sl).mean()))
 order = np.argsort(end)[-5:]
 print("last finishers: ", [(int(t[i, 4] >> np.uint64(32)), int(t[i, 4] & np.uint64(0xffffffff)), round(float(start[i]), 1), round(float(end[i]), 1)) for i in order])

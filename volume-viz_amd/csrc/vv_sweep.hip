@@ -27,6 +27,8 @@
 #include "vv_device.h"
 #include "vv_kernels.h"
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 
 namespace vv {
@@ -37,7 +39,7 @@ constexpr int kTfBytes = 4096;
 constexpr int kCtlBytes = 2048;
 constexpr int kRingOff = kTfBytes + kCtlBytes;
 constexpr int kLdsMax = 160 * 1024;
-constexpr int kMaxChunks = 32;                 // rows (= LDS-DMA pieces) per slice image
+constexpr int kMaxChunks = 60;                 // rows (= LDS-DMA instructions) per slice image: a group's must fit the 6-bit vmcnt
 constexpr int kPage = 1024;                    // the ring is handed out in pages
 constexpr int kPages = (kLdsMax - kRingOff) / kPage;
 constexpr int kTab = 32;                       // slices the ring can hold at once (table entries)
@@ -48,12 +50,14 @@ typedef int __attribute__((ext_vector_type(2))) i2v;
 struct Ctl {                                   // control block in LDS
     int landed[4];                             // per loader wave: its rows of the slices k < landed[w] have landed (unused: kInf)
     int kmin, kmax;                            // slice range of the tile (sweep order)
-    int err, pad_;
+    int err;
+    int alloc;                                 // index of the next group to be given its place in the ring
     int progress[16];                          // per consumer wave: slices k < progress[w] are released
     i2v tab[kTab];                            // per slice k (entry k % kTab): byte address of voxel (x 0, row 0) of its image, row pitch
     int box[kTab][4];                          // per slice: x0, x1, r0, r1 held (instrumented builds check against it)
     int owner[kPages + 2];                     // per ring page: the slice whose image occupies it
     int sink[64];                              // where the prefetch wave's 4-byte loads land
+    int dbg[4][8];                             // debug builds: what each loader wave is doing
 };
 static_assert(sizeof(Ctl) <= kCtlBytes, "control block");
 
@@ -125,6 +129,13 @@ __device__ __forceinline__ bool any_(bool p) { return __builtin_amdgcn_ballot_w6
 __device__ __forceinline__ int wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
 __device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
 
+// volatile vector loads / stores in the LDS address space (through a generic pointer hipcc falls back to flat_load
+// with a full s_waitcnt: hundreds of cycles per access)
+typedef int __attribute__((ext_vector_type(4))) i4v_;
+typedef int __attribute__((ext_vector_type(2))) i2v_;
+__device__ __forceinline__ i4v_ lds_load_i4(const void *p) { return *(const volatile __attribute__((address_space(3))) i4v_ *)p; }
+__device__ __forceinline__ i2v_ lds_load_i2(const void *p) { return *(const volatile __attribute__((address_space(3))) i2v_ *)p; }
+__device__ __forceinline__ void lds_store_i2(void *p, i2v_ v) { *(volatile __attribute__((address_space(3))) i2v_ *)p = v; }
 __device__ __forceinline__ int lds_load_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store_i(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -185,10 +196,16 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         const int t = S.order[blockIdx.x];
         trow = t / S.ntx; tcol = t % S.ntx;
     } else {
+        // Centre-out: the tiles in the middle of the frame march the longest rays, the ones at its rim are short or
+        // empty; dispatching the long ones first keeps the end of the launch from waiting for a few late, long tiles.
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-        trow = (j / S.ntx) * 8 + xcd; tcol = j % S.ntx;
+        const int rr = (j / S.ntx) * 8 + xcd, rc = j % S.ntx;             // rank of the tile row / column
+        if (rr >= S.nty) return;                                          // block-uniform, before any barrier
+        const int cy = (S.nty - 1) >> 1, cx = (S.ntx - 1) >> 1;
+        trow = (rr & 1) ? cy + ((rr + 1) >> 1) : cy - (rr >> 1);
+        tcol = (rc & 1) ? cx + ((rc + 1) >> 1) : cx - (rc >> 1);
     }
-    if (trow >= S.nty) return;                                        // block-uniform, before any barrier
+    if (trow >= S.nty || trow < 0 || tcol < 0 || tcol >= S.ntx) return;   // block-uniform, before any barrier
     const int tile_w = S.wx * 32, tile_h = S.wy * 2;
     const int x0 = tcol * tile_w;
     const int y0 = S.y0 + (trow / S.rows_per_band) * S.band_stride_px + (trow % S.rows_per_band) * tile_h;
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         lds_tf[i] = e.x; lds_tf[256 + i] = e.y; lds_tf[512 + i] = e.z; lds_tf[768 + i] = e.w;
     }
     if (threadIdx.x < 16) ctl->progress[threadIdx.x] = kInf;
-    if (threadIdx.x == 16) { ctl->kmin = kInf; ctl->kmax = -1; ctl->err = 0; }
+    if (threadIdx.x == 16) { ctl->kmin = kInf; ctl->kmax = -1; ctl->err = 0; ctl->alloc = 0; }
     if (threadIdx.x >= 32 && threadIdx.x < 36) ctl->landed[threadIdx.x - 32] = (int)threadIdx.x - 32 < S.nl ? 0 : kInf;
     for (int i = threadIdx.x; i < kPages + 2; i += blockDim.x) ctl->owner[i] = -1;
     __syncthreads();
@@ -241,15 +258,13 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         const uint64_t Ss = MAJOR == 2 ? V.slice_bytes : V.row_bytes;       // bytes between slices
         __syncthreads();
         const int kmin = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmin)), kmax = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmax));
-        // the loaders' few instructions must not queue behind the consumers' arithmetic on their SIMD
-        __builtin_amdgcn_s_setprio(3);
         if (lw >= S.nl) {
             // ---- prefetch wave (optional): pulls the footprints of the slices ahead of the loaders from HBM into the
             // XCD's L2, one 4-byte load per 128-byte line into a sink in LDS (no destination register that a late
             // load could clobber), so that a ring fill lands in a few hundred cycles instead of thousands. ----
             int kp = kmin, idle = 0;
             while (kp <= kmax) {
-                const i4v l4 = *(volatile i4v *)ctl->landed;
+                const i4v l4 = lds_load_i4(ctl->landed);
                 const int ld = __builtin_amdgcn_readfirstlane(min(min(l4.x, l4.y), min(l4.z, l4.w)));
                 if (ld >= kInf) break;
                 if (kp >= ld + S.lead) {
@@ -280,98 +295,119 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return;
         }
-        // ---- loader wave lw: rows lw, lw + nl, ... of every slice's image.  The ring is handed out in 1 KiB pages, in
-        // slice order, as a circular first-in-first-out buffer: slice k takes ceil(rows * pitch / 1 KiB) pages at `head`,
-        // or at page 0 when they do not fit before the end.  Every loader wave derives the same positions from the same
-        // footprints, so the waves never talk to each other; a slice is complete when all of them have landed their rows
-        // (consumers take the minimum of landed[]).  A page may be overwritten once the slice that owns it is released by
-        // every consumer wave. ----
-        if (lane == 0) lds_store_i(&ctl->landed[lw], kmin);             // slices before kmin are never asked for
-        int kn = kmin, kq = kmin;            // next slice to issue; oldest slice issued and not yet confirmed
-        int head = 0, pend = 0, outstanding = 0, idle = 0;
-        unsigned long long qn = 0, qk = 0;   // LDS-DMA instructions and slices of the pending groups, 8 bits each, oldest lowest
+        // ---- loader wave lw: every nl-th group of `group` slices.  The ring is handed out in 1 KiB pages, in slice
+        // order, as a circular first-in-first-out buffer: a group takes ceil(slices * rows * pitch / 1 KiB) pages at
+        // `head`, or at page 0 when they do not fit before the end.  Every loader wave derives the same positions from
+        // the same footprints (it runs the footprints of the other waves' groups too: a few dozen instructions), so
+        // the waves never talk to each other.  Wave w publishes landed[w] = the first slice it has not confirmed yet
+        // (its oldest pending group, else the next group it will issue); everything before the minimum over the
+        // waves has landed.  A page may be overwritten once the group that owns it is released by every consumer wave.
+        // A group shares one footprint (the union over its slices), one allocation and one confirmation: per slice
+        // the loaders' bookkeeping would cost more than the copies themselves. ----
+        const int G = S.group;
+        int gi = 0;                          // index of the next group in the deterministic walk
+        int kn = kmin;                       // its first slice
+        int head = 0, idle = 0;
+        int pk = -1, pn = 0;                 // first slice and instruction count of this wave's pending group (-1: none)
         bool bail = false;
         unsigned long long t_issue = 0, t_land = 0, t_pub = 0, t_idle = 0, tt = 0;
         const unsigned long long t_pro = INSTR ? __builtin_readcyclecounter() - t_start : 0ull;
+        // the first group that is mine
+        auto group_shape = [&](int k0, int &ke, Foot &f) {
+            ke = min(k0 + G - 1, kmax);
+            const int sa = kmul * k0 + kadd, sb = kmul * ke + kadd;
+            const Foot fa = footprint(FL, sa, nx, nr), fb = footprint(FL, sb, nx, nr);
+            f.x0 = __builtin_amdgcn_readfirstlane(min(fa.x0, fb.x0)); f.x1 = __builtin_amdgcn_readfirstlane(max(fa.x1, fb.x1));      // uniform by construction:
+            f.r0 = __builtin_amdgcn_readfirstlane(min(fa.r0, fb.r0)); f.r1 = __builtin_amdgcn_readfirstlane(max(fa.r1, fb.r1));      // scalar loops and branches
+        };
+        if (lane == 0) lds_store_i(&ctl->landed[lw], kmin);
         for (;;) {
             if (INSTR) tt = __builtin_readcyclecounter();
-            // ---- 1. issue the next group of up to `group` slices if the ring has room for it.  A group shares one
-            //         footprint (the union over its slices), one allocation and one confirmation: the per-slice cost of
-            //         the loaders' bookkeeping would otherwise exceed the time the copies themselves take. ----
-            bool issued_now = false;
-            if (kn <= kmax && pend < S.depth) {
+            if (kn > kmax && pk < 0) break;
+            // ---- groups of the other waves: only their place in the ring ----
+            if (kn <= kmax && (gi % S.nl) != lw) {
+                int ke; Foot f;
+                group_shape(kn, ke, f);
+                const int ncell = min((f.x1 >> 5) - (f.x0 >> 5) + 1, S.pxc), nrows = min(f.r1 - f.r0 + 1, S.ry);
+                const int np = ((ke - kn + 1) * nrows * ncell * 128 + kPage - 1) / kPage;
+                head = (head + np <= kPages ? head : 0) + np;
+                kn = ke + 1; ++gi;
+                if (pk < 0 && lane == 0) lds_store_i(&ctl->landed[lw], min(kn, kmax + 1));     // nothing of mine before kn is missing
+                continue;
+            }
+            // ---- my pending group first: it must be confirmed before my next one is issued (one group's instructions
+            //      nearly fill the 6-bit vmcnt) ----
+            if (pk >= 0) {
+                wait_vm<0>();
+                pk = -1;
+                if (lane == 0) lds_store_i(&ctl->landed[lw], min(kn, kmax + 1));               // all my groups before kn have landed
+                if (INSTR) t_land += __builtin_readcyclecounter() - tt;
+                continue;
+            }
+            // ---- my next group: wait for room in the ring, then issue it ----
+            {
                 const int pr = max(__builtin_amdgcn_readlane(row16_min(lds_load_i(&ctl->progress[lane & 15])), 15), kmin);
                 if (pr >= kInf) { bail = true; break; }                 // every consumer wave has left the ring
-                const int ke = min(kn + S.group - 1, kmax), ng = ke - kn + 1;
-                const int sa = kmul * kn + kadd, sb = kmul * ke + kadd;
-                const Foot fa = footprint(FL, sa, nx, nr), fb = footprint(FL, sb, nx, nr);
-                Foot f;
-                f.x0 = __builtin_amdgcn_readfirstlane(min(fa.x0, fb.x0)); f.x1 = __builtin_amdgcn_readfirstlane(max(fa.x1, fb.x1));      // uniform by construction:
-                f.r0 = __builtin_amdgcn_readfirstlane(min(fa.r0, fb.r0)); f.r1 = __builtin_amdgcn_readfirstlane(max(fa.r1, fb.r1));      // scalar loops and branches
-                const int c0 = f.x0 >> 5;
+                int ke; Foot f;
+                group_shape(kn, ke, f);
+                const int ng = ke - kn + 1, c0 = f.x0 >> 5;
                 int ncell = (f.x1 >> 5) - c0 + 1, nrows = f.r1 - f.r0 + 1;
                 if (ncell > S.pxc || nrows > S.ry) { if (lane == 0) lds_store_i(&ctl->err, 2); ncell = min(ncell, S.pxc); nrows = min(nrows, S.ry); }
                 const int pitch = ncell * 128, img_bytes = nrows * pitch;
                 const int np = (ng * img_bytes + kPage - 1) / kPage;
                 const int pos = head + np <= kPages ? head : 0;
-                const int n_my = ng * ((nrows - lw + S.nl - 1) / S.nl);
-                bool ok = ke - pr < kTab && (pend == 0 || outstanding + n_my <= 60);
+                // Places are given out in group order (ctl->alloc passes from wave to wave): a later group that took its
+                // pages first could sit on pages an earlier group needs while the consumers wait for that earlier group.
+                bool ok = ke - pr < kTab && __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->alloc)) == gi;
                 if (ok) {
                     bool busy = false;
-                    for (int b0 = 0; b0 < np; b0 += 64) {
-                        if (b0 + lane < np) { const int o = lds_load_i(&ctl->owner[pos + b0 + lane]); busy = busy || !(o < pr || o == ke); }
-                    }
+                    for (int b0 = 0; b0 < np; b0 += 64)
+                        if (b0 + lane < np) busy = busy || !(lds_load_i(&ctl->owner[pos + b0 + lane]) < pr);
                     ok = !any_(busy);
                 }
-                if (ok) {
-                    for (int b0 = 0; b0 < np; b0 += 64)
-                        if (b0 + lane < np) lds_store_i(&ctl->owner[pos + b0 + lane], ke);
-                    const int img = kRingOff + pos * kPage;
-                    if (lane < ng) {
-                        *(volatile i2v *)&ctl->tab[(kn + lane) & (kTab - 1)] = i2v{img + lane * img_bytes - f.r0 * pitch - c0 * 128, pitch};
-                        if (INSTR) { int *bx = ctl->box[(kn + lane) & (kTab - 1)]; bx[0] = c0 * 32; bx[1] = (c0 + ncell) * 32 - 1; bx[2] = f.r0; bx[3] = f.r0 + nrows - 1; }
-                    }
-                    const char *gs = (const char *)V.data + (int64_t)sa * (int64_t)Ss + ((uint64_t)f.r0 + lw) * Sr + (uint64_t)c0 * 128u + (uint32_t)lane * 16u;
-                    const int64_t gstep = (int64_t)kmul * (int64_t)Ss;
-                    int ls = img + lw * pitch;
-                    const bool mine = lane < 8 * ncell;
+                if (!ok) {
+#ifdef VV_SWEEP_DEBUG
+                    if (lane == 0) { int *d = ctl->dbg[lw]; d[0] = kn; d[1] = ke; d[2] = pr; d[3] = pos; d[4] = np; d[5] = head; d[6] = gi; d[7] = idle; }
+#endif
+                    // no room: wait without taking issue slots from the consumers that have to make it
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_s_sleep(4);
+                    if (INSTR) t_idle += __builtin_readcyclecounter() - tt;
+                    if (++idle > (1 << 22)) { if (lane == 0) lds_store_i(&ctl->err, 1); bail = true; break; }
+                    continue;
+                }
+                idle = 0;
+                __builtin_amdgcn_s_setprio(3);       // the copies are on every consumer's critical path: issue them ahead of the arithmetic
+                for (int b0 = 0; b0 < np; b0 += 64)
+                    if (b0 + lane < np) lds_store_i(&ctl->owner[pos + b0 + lane], ke);
+                const int img = kRingOff + pos * kPage;
+                if (lane < ng) {
+                    lds_store_i2(&ctl->tab[(kn + lane) & (kTab - 1)], i2v{img + lane * img_bytes - f.r0 * pitch - c0 * 128, pitch});
+                    if (INSTR) { int *bx = ctl->box[(kn + lane) & (kTab - 1)]; bx[0] = c0 * 32; bx[1] = (c0 + ncell) * 32 - 1; bx[2] = f.r0; bx[3] = f.r0 + nrows - 1; }
+                }
+                if (lane == 0) lds_store_i(&ctl->alloc, gi + 1);         // the next group may take its place (after the owner marks above: LDS is in order)
+                const int sa = kmul * kn + kadd;
+                const char *gp = (const char *)V.data + (int64_t)sa * (int64_t)Ss + (uint64_t)f.r0 * Sr + (uint64_t)c0 * 128u + (uint32_t)lane * 16u;
+                const int64_t gstep = (int64_t)kmul * (int64_t)Ss - (int64_t)nrows * (int64_t)Sr;    // last row of a slice -> first row of the next
+                int lb = img;
+                if (lane < 8 * ncell) {              // one exec mask for the whole group
 #pragma unroll 1
                     for (int j = 0; j < ng; ++j) {
-                        const char *gp = gs;
-                        int lb = ls;
 #pragma unroll 1
-                        for (int rr = lw; rr < nrows; rr += S.nl) {
-                            if (mine)
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
-                                                                 (__attribute__((address_space(3))) void *)(lds + lb), 16, 0, 0);
-                            gp += Sr * S.nl; lb += pitch * S.nl;
+                        for (int rr = 0; rr < nrows; ++rr) {
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                                             (__attribute__((address_space(3))) void *)(lds + lb), 16, 0, 0);
+                            gp += Sr; lb += pitch;
                         }
-                        gs += gstep; ls += img_bytes;
+                        gp += gstep;
                     }
-                    qn |= (unsigned long long)n_my << (8 * pend);
-                    qk |= (unsigned long long)ng << (8 * pend);
-                    ++pend; outstanding += n_my; head = pos + np; kn = ke + 1;
-                    issued_now = true; idle = 0;
-                    if (INSTR && lane == 0 && lw == 0) atomicAdd(counter + 5, (unsigned long long)ng * nrows * ncell * 128ull);
-                    if (INSTR) t_issue += __builtin_readcyclecounter() - tt;
                 }
+                __builtin_amdgcn_s_setprio(0);
+                pk = kn; pn = ng * nrows;
+                head = pos + np; kn = ke + 1; ++gi;
+                if (INSTR && lane == 0) atomicAdd(counter + 5, (unsigned long long)ng * nrows * ncell * 128ull);
+                if (INSTR) t_issue += __builtin_readcyclecounter() - tt;
             }
-            // ---- 2. confirm the oldest pending slice: when `depth` slices are pending, or nothing could be issued.  Its rows have
-            //         landed once only the younger slices' instructions are outstanding (vmcnt retires in issue order). ----
-            if (pend > 0 && (pend >= S.depth || !issued_now)) {
-                const int n0 = (int)(qn & 255ull);
-                wait_vm_n(outstanding - n0);
-                kq += (int)(qk & 255ull);
-                if (lane == 0) lds_store_i(&ctl->landed[lw], kq);
-                qn >>= 8; qk >>= 8; --pend; outstanding -= n0; idle = 0;
-                if (INSTR) t_land += __builtin_readcyclecounter() - tt;
-                continue;
-            }
-            if (issued_now) continue;
-            if (kn > kmax) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (INSTR) t_idle += __builtin_readcyclecounter() - tt;
-            if (++idle > (1 << 22)) { if (lane == 0) lds_store_i(&ctl->err, 1); bail = true; break; }
         }
         wait_vm<0>();                     // nothing of this wave may land in LDS after it has gone
         // open the gate for good: a consumer that asked for more than kmax would otherwise wait forever (it cannot,
@@ -381,7 +417,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             atomicAdd(counter + 8, t_issue); atomicAdd(counter + 9, t_land); atomicAdd(counter + 10, t_pub); atomicAdd(counter + 11, t_idle);
             atomicAdd(counter + 12, t_pro);
         }
-        (void)bail;
+        (void)bail; (void)pn;
         return;
     }
 
@@ -438,7 +474,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
     int tail = 0;                             // wave-uniform: the wave has left the ring (its live rays have all terminated early)
     int pw = 0;                               // published progress of this wave
     int kl = kmin;                            // slices k < kl have landed
-    int stall_run = 0;
+    int stall_run = 0, n_iter = 0, n_stall = 0;
     const int needoff = S.sgn > 0 ? 1 : 0;
     unsigned long long t_stall = 0, t_c0 = __builtin_readcyclecounter(), t_s = 0;
     const unsigned long long t_loop0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -466,7 +502,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             if (lane == 0) lds_store_i(&ctl->progress[wave], kInf);
         }
         tail = __builtin_amdgcn_readfirstlane(tail);
-        if (!tail) { const i4v l4 = *(volatile i4v *)ctl->landed; kl = min(min(l4.x, l4.y), min(l4.z, l4.w)); }
+        if (!tail) { const i4v l4 = lds_load_i4(ctl->landed); kl = min(min(l4.x, l4.y), min(l4.z, l4.w)); }
         asm volatile("" ::: "memory");        // the flag is read before any slice data of this step
 
         // ---- candidate: sample i of the open chunk (kernel.cu:136-141) ----
@@ -500,12 +536,17 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             if (any_(alive && i == 0)) continue;         // an empty chunk: open the next one
             // nothing to do until the loaders catch up
             if (INSTR) ++stalls;
+            ++n_stall;
             __builtin_amdgcn_s_sleep(1);
             if (INSTR) t_stall += __builtin_readcyclecounter() - t_s;
             if (++stall_run > (1 << 21)) {               // watchdog: a wrong pixel beats a hung GPU
 #ifdef VV_SWEEP_DEBUG
                 {
                     const int mn = wave_min_fast(open ? need : kInf);
+                    if (lane == 0) {
+                        for (int w = 0; w < S.nl; ++w) printf("  loader %d: landed %d | waiting: kn %d ke %d pr %d pos %d np %d head %d gi %d idle %d | owners %d %d %d\n", w, ctl->landed[w], ctl->dbg[w][0], ctl->dbg[w][1], ctl->dbg[w][2], ctl->dbg[w][3], ctl->dbg[w][4], ctl->dbg[w][5], ctl->dbg[w][6], ctl->dbg[w][7],
+                            ctl->owner[ctl->dbg[w][3]], ctl->owner[ctl->dbg[w][3] + 1], ctl->owner[ctl->dbg[w][3] + ctl->dbg[w][4] - 1]);
+                    }
                     if (lane == 0) printf("watchdog tile (%d,%d) wave %d: kl %d loaded %d min need %d pw %d kmin %d kmax %d progress %d %d %d %d %d %d %d %d %d %d %d %d\n", tcol, trow, wave, kl,
                         lds_load_i(&ctl->landed[0]), mn, pw, kmin, lds_load_i(&ctl->kmax), ctl->progress[0], ctl->progress[1], ctl->progress[2], ctl->progress[3], ctl->progress[4], ctl->progress[5],
                         ctl->progress[6], ctl->progress[7], ctl->progress[8], ctl->progress[9], ctl->progress[10], ctl->progress[11]);
@@ -516,13 +557,13 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             }
             continue;
         }
-        stall_run = 0;
+        stall_run = 0; ++n_iter;
         if (INSTR) slots += 64;
 
         // ---- eight corners ----
         uint32_t idx;
         if (!tail) {
-            const i2v T0 = *(volatile i2v *)&ctl->tab[k0 & (kTab - 1)], T1 = *(volatile i2v *)&ctl->tab[(k0 + kmul) & (kTab - 1)];
+            const i2v T0 = lds_load_i2(&ctl->tab[k0 & (kTab - 1)]), T1 = lds_load_i2(&ctl->tab[(k0 + kmul) & (kTab - 1)]);
             const int x4 = (int)(ix << 2);
             const char *p0 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)T0.y) + (T0.x + x4));
             const char *p1 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)T1.y) + (T1.x + x4));
@@ -581,7 +622,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         unsigned long long *t = S.trace + 8ull * blockIdx.x;
         t[0] = t_blk0; t[1] = t_loop0; t[2] = __builtin_amdgcn_s_memrealtime();
         t[3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63508);
-        t[4] = ((unsigned long long)trow << 32) | (unsigned)tcol; t[5] = ((unsigned long long)(unsigned)lds_load_i(&ctl->kmax) << 32) | (unsigned)kmin; t[6] = (unsigned long long)chunks; t[7] = 1;
+        t[4] = ((unsigned long long)trow << 32) | (unsigned)tcol; t[5] = ((unsigned long long)(unsigned)lds_load_i(&ctl->kmax) << 32) | (unsigned)kmin; t[6] = ((unsigned long long)(unsigned)n_stall << 32) | (unsigned)n_iter; t[7] = 1;
     }
 
     if (in_frame) {
@@ -640,13 +681,15 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     using namespace sweepk;
     SweepArgs &S = A.sweep;
     S.enabled = 0;
+    const bool verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
+#define VV_NO(why) do { if (verbose) fprintf(stderr, "sweep: not used (%s)\n", why); return; } while (0)
     const FrameParams &P = A.P;
     const VolumeView &V = A.V;
-    if (A.phong || A.V_type != VV_VOXEL_F32 || P.slice_type != SLICE_NONE) return;
-    if (P.ray_mode != VV_RAYS_ANALYTIC || P.quantize8) return;
-    if ((V.row_bytes & 15u) || (V.slice_bytes & 15u) || ((uintptr_t)V.data & 15u)) return;
-    if (!(P.step[0] == P.step[1] && P.step[1] == P.step[2])) return;      // samples of a chunk must stay on the ray's line
-    if (P.W < 2 || P.H < 2 || n_rows_px < 1) return;
+    if (A.phong || A.V_type != VV_VOXEL_F32 || P.slice_type != SLICE_NONE) VV_NO("shaded, u8 or cutting plane");
+    if (P.ray_mode != VV_RAYS_ANALYTIC || P.quantize8) VV_NO("rays from images / quantised");
+    if ((V.row_bytes & 15u) || (V.slice_bytes & 15u) || ((uintptr_t)V.data & 15u)) VV_NO("rows not 16-byte aligned");
+    if (!(P.step[0] == P.step[1] && P.step[1] == P.step[2])) VV_NO("anisotropic step");      // samples of a chunk must stay on the ray's line
+    if (P.W < 2 || P.H < 2 || n_rows_px < 1) VV_NO("degenerate frame");
     const double n[3] = {(double)V.nx, (double)V.ny, (double)V.nz};
     double h[3], E[3];
     bool outside = false;
@@ -655,7 +698,7 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
         E[a] = ((double)P.cam_pos[a] * h[a] + 0.5) * n[a] - 0.5;
         if (fabs((double)P.cam_pos[a]) > (double)P.scale[a] * 1.0001) outside = true;
     }
-    if (!outside) return;                                                 // eye inside the cube: front = (0,0,0) rays (kernel.cu:317-321 quirk)
+    if (!outside) VV_NO("eye inside the cube");                                                 // eye inside the cube: front = (0,0,0) rays (kernel.cu:317-321 quirk)
     auto dirD = [&](double px, double py, double D[3]) {
         const double sx = ((2.0 * (px + 0.5)) / P.W - 1.0) * P.tan_half_x, sy = ((2.0 * (py + 0.5)) / P.H - 1.0) * P.tan_half_y;
         for (int a = 0; a < 3; ++a) D[a] = (P.side[a] * sx + P.up[a] * sy + P.look[a]) * h[a] * n[a];
@@ -674,11 +717,11 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
         if (lo > 0.0 ? !(E[ax] < -1.5) : !(E[ax] > n[ax] + 1.5)) continue;
         if (q > best_q) { best_q = q; best = ax; best_sgn = lo > 0.0 ? 1 : -1; }
     }
-    if (!best || best_q < 0.35) return;
+    if (!best || best_q < 0.35) VV_NO("no sweep axis: rays cross the x-y and x-z planes both ways or too flatly, or the eye is beside the slices");
     // sample spacing along the sweep axis, in slices: beyond ~3 whole slices would be streamed for nothing
     {
         const double dz = (double)P.step[best] * (double)P.inv_scale[best] * n[best];
-        if (!(dz <= 3.0)) return;
+        if (!(dz <= 3.0)) VV_NO("samples more than 3 slices apart");
     }
     const int xa = 0, ra = best == 2 ? 1 : 2, sa = best;
     const int nr = (int)n[ra], ns = (int)n[sa];
@@ -695,7 +738,7 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     if (const char *e = getenv("VV_SWEEP_DEPTH")) { int t = atoi(e); if (t >= 1 && t <= 8) S.depth = t; }
     S.lead = 0;                              // slices the prefetch wave runs ahead of the landed ones (0: no prefetch wave)
     if (const char *e = getenv("VV_SWEEP_LEAD")) { int t = atoi(e); if (t >= 0 && t <= 64) S.lead = t; }
-    if (S.wx * S.wy + S.nl + (S.lead > 0 ? 1 : 0) > 16) return;
+    if (S.wx * S.wy + S.nl + (S.lead > 0 ? 1 : 0) > 16) VV_NO("too many waves");
     const bool forced = getenv("VV_SWEEP_WX") || getenv("VV_SWEEP_WY");
     for (;;) {
         S.nc = S.wx * S.wy;
@@ -720,7 +763,7 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
                 double hx_lo = INFINITY, hx_hi = -INFINITY, hr_lo = INFINITY, hr_hi = -INFINITY, ex = 0.0, er = 0.0;
                 for (int end = 0; end < 2; ++end) {
                     const double sl = end ? ns : 0;
-                    const double z0 = sl - 1.5 - (S.group - 1) - E[sa], z1 = sl + 1.0 + (S.group - 1) - E[sa];   // a group's slab, whichever way it extends
+                    const double z0 = sl - 1.5 - (S.sgn < 0 ? S.group - 1 : 0) - E[sa], z1 = sl + 1.0 + (S.sgn > 0 ? S.group - 1 : 0) - E[sa];   // a group's slab: it extends along the sweep
                     const double xs[4] = {mxl * z0, mxl * z1, mxh * z0, mxh * z1}, rs[4] = {mrl * z0, mrl * z1, mrh * z0, mrh * z1};
                     const double xl = *std::min_element(xs, xs + 4), xh = *std::max_element(xs, xs + 4);
                     const double rl = *std::min_element(rs, rs + 4), rh = *std::max_element(rs, rs + 4);
@@ -739,15 +782,27 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
         S.ry = std::min(S.ry, nr + 1);
         S.slot_bytes = S.pxc * 128 * S.ry;                               // the largest image of a slice
         S.ring = (kPages * kPage) / S.slot_bytes;                        // slices of that size the ring holds (it holds more of the smaller ones)
-        if (S.pxc <= 8 && S.ry <= kMaxChunks && S.ring >= 5) break;
+        if (S.pxc <= 8 && S.ry <= kMaxChunks && S.ring >= 5) break;       // (>= 3 groups of one slice, see below, with room to spare)
         // footprint too large for the LDS (sparse pixels): smaller tiles, else no sweep
-        if (forced) return;
-        if (S.wy > 2) S.wy -= 1; else if (S.wx > 1) { S.wx -= 1; S.wy = 4; } else return;
+        if (verbose) fprintf(stderr, "sweep: tile %dx%d waves needs pxc %d ry %d ring %d\n", S.wx, S.wy, S.pxc, S.ry, S.ring);
+        if (forced) VV_NO("forced tile shape does not fit");
+        if (S.wy > 2) S.wy -= 1; else if (S.wx > 1) { S.wx -= 1; S.wy = 4; } else VV_NO("footprint does not fit the LDS");
     }
     (void)nr;
+    // A sample may interpolate between the last slice of one group and the first of the next, and the loaders can only
+    // refill behind both: three groups of the largest size must fit or the ring can lock up.  One row of slack per group
+    // for the rounding to pages.
+    {
+        const int gmax = (kPages * kPage) / (3 * (S.slot_bytes + kPage));
+        if (gmax < 1) VV_NO("three groups do not fit the ring");
+        S.group = std::min(S.group, gmax);
+        if (S.group * S.ry > 62) S.group = std::max(1, 62 / S.ry);             // a group's copies must fit the 6-bit vmcnt
+    }
     S.lds_bytes = kRingOff + kPages * kPage;
     S.order = nullptr; S.n_order = 0; S.trace = nullptr;
     S.enabled = 1;
+    if (verbose) fprintf(stderr, "sweep: axis %d sgn %d, tile %dx%d px (%d+%d waves), image <= %d cells x %d rows, group %d, %d x %d tiles\n", S.major, S.sgn, 32 * S.wx, 2 * S.wy, S.nc, S.nl, S.pxc, S.ry, S.group, S.ntx, S.nty);
+#undef VV_NO
 }
 
 } // namespace vv
