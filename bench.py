@@ -100,7 +100,11 @@ def main():
 
     n, W, H, steps = workload(args, world)
     ctx = vv.Context(local)
-    stream = torch.cuda.current_stream().cuda_stream
+    # everything (kernels, events, the gather) runs on one non-default stream: vv_render only enqueues on a caller
+    # stream (with no stream it would run on the context's own stream and synchronise every frame)
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = vv.stream_handle(tstream)
 
     # ---- synthetic volume, generated and promoted on the device, replicated per GPU ----
     v8 = torch.empty(n * n * n, dtype=torch.uint8, device=dev)

@@ -79,6 +79,13 @@ typedef enum {
 
 typedef struct vv_context vv_context;
 
+/* The `stream` argument of the entry points below is a hipStream_t passed as void*:
+ *   NULL                     the context's own stream; the call returns when the work is complete (the reference's
+ *                            synchronous contract, kernel.cu:452,517);
+ *   VV_STREAM_DEFAULT_ASYNC  the device's default (null) stream, enqueue only;
+ *   any other handle         that stream, enqueue only: the caller synchronises.                                  */
+#define VV_STREAM_DEFAULT_ASYNC ((void *)1)
+
 typedef enum { VV_VOXEL_U8 = 0, VV_VOXEL_F32 = 1 } vv_voxel_type;
 
 /* Trilinear reconstruction model (what tex3D does in kernel.cu:102,589,628).
@@ -160,7 +167,8 @@ int  vv_set_transfer_function(vv_context *ctx, const float tf[1024]);
  * enqueues slices [z0, z0+n) on an internal copy stream (directly if `src` is pinned host
  * memory, through a pinned double buffer otherwise) and returns; src_type may be VV_VOXEL_U8
  * while the volume is VV_VOXEL_F32, in which case the slices are promoted (v/255) on the
- * device.  end waits for the copies.  Slices may arrive in any order.                      */
+ * device.  end waits for the copies.  Slices may arrive in any order.  A slices call returns once the source
+ * buffer has been read (pinned sources are copied from directly), so the caller may refill it at once.          */
 int  vv_load_volume_stream_begin(vv_context *ctx, int voxel_type, int nx, int ny, int nz,
                                  const float tf[1024]);
 int  vv_load_volume_stream_slices(vv_context *ctx, const void *src, int src_type, int z0, int nslices);
@@ -298,6 +306,9 @@ int                vv_debug_counters(vv_context *ctx, unsigned long long out[16]
  * 8 words per block (start, march start, end in 10 ns ticks; hardware ids; tile; slice range; chunks; valid).
  * Returns the number of blocks copied. */
 int                vv_debug_sweep_trace(vv_context *ctx, unsigned long long *out, int max_blocks);
+/* The VV_* developer knobs of the environment are read when a context is created and at every volume load, never
+ * per frame; this reads them again (tests that flip a knob between two frames of one volume). */
+int                vv_reread_env(vv_context *ctx);
 int                vv_volume_dims(const vv_context *ctx, int dims[3], int *voxel_type);
 
 #ifdef __cplusplus

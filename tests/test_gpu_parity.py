@@ -548,7 +548,7 @@ def test_prepare_layouts_and_device_bytes(ctx, monkeypatch):
     vol = O.noise_u8(130, 129, 131, 3).astype(np.float32) / np.float32(255)        # > 2 M voxels: bricks by policy
     ctx.load_volume(vol, tf)
     b = ctx.device_bytes()
-    assert b[0] == vol.nbytes + (129 + 1) * 130 * 4 + 16 and b[1] == 0 and b[2] == 0      # + one slice + one row + 16 B of padding
+    assert b[0] == vol.nbytes + (129 + 2) * 130 * 4 + 4096 and b[1] == 0 and b[2] == 0    # + one slice + two rows + 4 KiB of padding
     assert ctx.prepare_layouts(vv.LAYOUT_BRICKED | vv.LAYOUT_ZPAIR) == 3
     b = ctx.device_bytes()
     nbx, nby, nbz = (130 + 3) // 4, 129 // 4 + 1, 131 // 4 + 1
@@ -573,7 +573,7 @@ def test_prepare_layouts_and_device_bytes(ctx, monkeypatch):
     assert b[1] == (160 // 4) * (121 // 4 + 1) * (110 // 4 + 1) * 128 and b[2] == 110 * (121 + 1) * ((160 + 1) * 2 + 2)
     ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
     b = ctx.device_bytes()
-    assert b[0] == 64 + 16 + 4 + 16 and b[1] == 0 and b[2] == 0
+    assert b[0] == 64 + 16 + 2 * 4 + 4096 and b[1] == 0 and b[2] == 0
     with pytest.raises(vv.VolvizError):
         ctx.prepare_layouts(8)
 
@@ -593,13 +593,14 @@ def test_padded_pitch_layout(ctx, dims, dtype, monkeypatch):
     nx, ny, nz = dims
     row = nx * vol.itemsize + 32
     rows = ny + (1 if (ny * row) % 4096 == 0 else 0)
-    assert ctx.device_bytes()[0] == nz * rows * row + rows * row + row + 16
+    assert ctx.device_bytes()[0] == nz * rows * row + rows * row + 2 * row + 4096
     opts = vv.make_options(step=1 / 60, count_samples=True)
     for env in ({}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}):
         for k in ("VV_BRICKED", "VV_ZPAIR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        ctx.reread_env()                   # knobs are read at volume load, not per frame
         for cam, phong in ((vv.Camera(), False), (vv.Camera(), True), (_cam("b"), False), (_cam("c"), True)):
             got = ctx.render(75, 59, cam, phong=phong, options=opts)
             want, n = O.render(vol, tf, 75, 59, cam, phong=phong, options=opts)
@@ -610,13 +611,13 @@ def test_padded_pitch_layout(ctx, dims, dtype, monkeypatch):
                               O.slice(vol, 40, 33, 0.1, 0.2, 0.3, orientation=orient, fill=-1.0))
     # streamed upload ends in the same padded layout
     ctx.load_volume_streamed(((z, vol[z:z + 2]) for z in range(0, nz, 2)), vv.VOXEL_U8 if dtype == np.uint8 else vv.VOXEL_F32, nx, ny, nz, tf)
-    assert ctx.device_bytes()[0] == nz * rows * row + rows * row + row + 16
+    assert ctx.device_bytes()[0] == nz * rows * row + rows * row + 2 * row + 4096
     got = ctx.render(75, 59, _cam("c"), options=opts)
     want, _ = O.render(vol, tf, 75, 59, _cam("c"), options=opts)
     assert_frames_close(got, want, f"padded streamed {dims}")
     monkeypatch.setenv("VV_PITCH_PAD", "0")
     ctx.load_volume(vol, tf)
-    assert ctx.device_bytes()[0] == vol.nbytes + ny * nx * vol.itemsize + nx * vol.itemsize + 16
+    assert ctx.device_bytes()[0] == vol.nbytes + ny * nx * vol.itemsize + 2 * nx * vol.itemsize + 4096
 
 
 def test_bricked_copy_edges_and_reload(ctx, monkeypatch):
@@ -803,6 +804,7 @@ def test_volume_above_4gib(ctx, monkeypatch):
     # 64-bit layer addressing; VV_BRICKED=0 takes the linear layout with its 64-bit slice bases
     for bricked in ("1", "0"):
         monkeypatch.setenv("VV_BRICKED", bricked)
+        ctx.reread_env()                   # knobs are read at volume load, not per frame
         full = ctx.render(W, H, cam, options=opts)
         n_full = ctx.last_sample_count()
         assert (ctx.debug_counters()[2] > 0) == (bricked == "1")
@@ -823,6 +825,164 @@ def test_volume_above_4gib(ctx, monkeypatch):
     assert np.array_equal(ctx.slice_advanced(80, 80, m, fill=-1.0), O.slice_advanced(host, 80, 80, m, fill=-1.0))
     # free the 8.4 GB volume for the tests that follow
     ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
+
+
+def test_c1_reference_workload(ctx):
+    """BASELINE config C1, the reference's own size: 128^3 drawDefaultBrain volume (u8, as the reference stores it, and
+    promoted to f32), 512x512 frame, step 1/128 (the default), Head transfer function, camera (0,0,-4): the whole frame
+    and the executed-sample count against the oracle; Phong on the u8 volume too."""
+    vol8 = ctx.generate_default_brain(128, 128, 128)
+    assert np.array_equal(vol8, O.draw_default_brain(128, 128, 128))
+    tf = vv.transfer_preset(vv.TF_HEAD)
+    cam = vv.Camera()
+    for vol, phong in ((vol8, False), (vol8.astype(np.float32) / np.float32(255), False), (vol8, True)):
+        ctx.load_volume(vol, tf)
+        got = ctx.render(512, 512, cam, phong=phong, options=vv.make_options(count_samples=True), fill=0x5A)
+        n_got = ctx.last_sample_count()
+        want, n = O.render(vol, tf, 512, 512, cam, phong=phong, fill=0x5A)
+        assert_frames_close(got, want, f"C1 {vol.dtype} phong={phong}")
+        assert n_got == n and n > 5_000_000
+        assert (got[..., 3] > 0).mean() > 0.1
+
+
+def test_render_on_caller_stream_is_asynchronous_and_identical(ctx):
+    """A device frame on a caller's (non-default) stream is only enqueued; once that stream is drained it equals the
+    synchronous frame.  Also the explicit handle of the device's default stream (VV_STREAM_DEFAULT_ASYNC)."""
+    import torch
+    vol = O.noise_u8(96, 96, 96, 5)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    cam = _cam("b")
+    W, H = 300, 200
+    want = ctx.render(W, H, cam, fill=0)                                   # host buffer, synchronous
+    dev = torch.device("cuda", 0)
+    for handle_of in ("own", "default"):
+        frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+        if handle_of == "own":
+            ts = torch.cuda.Stream(device=dev)
+            h = vv.stream_handle(ts)
+            assert h not in (0, vv.STREAM_DEFAULT_ASYNC)
+        else:
+            ts = torch.cuda.default_stream(dev)
+            h = vv.stream_handle(ts)
+            assert h == vv.STREAM_DEFAULT_ASYNC
+        with torch.cuda.stream(ts):
+            for _ in range(3):
+                ctx.render_device(W, H, cam, frame.data_ptr(), stream=h)
+        ts.synchronize()
+        assert np.array_equal(frame.cpu().numpy(), want), handle_of
+
+
+def test_streamed_upload_reuses_one_pinned_buffer(ctx):
+    """vv_load_volume_stream_slices from ONE pinned slab buffer that the producer refills between calls (the C5 use
+    case): the call must not return before the copy engine has read the buffer."""
+    import torch
+    nx, ny, nz, per = 96, 80, 64, 8
+    vol = O.noise_u8(nx, ny, nz, 21)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    pin = torch.empty((per, ny, nx), dtype=torch.uint8).pin_memory()
+    view = pin.numpy()
+
+    def slabs():
+        for z0 in range(0, nz, per):
+            view[...] = vol[z0:z0 + per]          # refill the same pinned buffer
+            yield z0, view
+    ctx.load_volume_streamed(slabs(), vv.VOXEL_F32, nx, ny, nz, tf)       # u8 slabs promoted to f32 on the device
+    got = ctx.render(160, 120, _cam("a"), fill=0)
+    ref = vol.astype(np.float32) / np.float32(255)
+    want, _ = O.render(ref, tf, 160, 120, _cam("a"), fill=0)
+    assert_frames_close(got, want, "volume streamed from one reused pinned buffer")
+
+
+def test_slice_sampler_against_torch_grid_sample(ctx):
+    """Independent cross-check of the texture model (no reference fixture can exist for it): vv_slice in
+    VV_FILTER_EXACT mode against torch.nn.functional.grid_sample (trilinear, align_corners=False, border
+    padding) evaluated in fp32 on the GPU.  Normalised texture coordinate x maps to voxel space as x*N - 0.5 in both
+    (CUDA Programming Guide, "Linear Filtering": tex(x) with xB = x - 0.5 in unnormalised texel units; clamp
+    addressing = border padding).  Tolerance 1e-6 absolute on values in [0, 1]: the interpolation order differs."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    nz, ny, nx = 40, 52, 64
+    vol = rng.random((nz, ny, nx), dtype=np.float32)
+    ctx.load_volume(vol, vv.transfer_preset(vv.TF_HEAD))
+    h = w = 128
+    dev = torch.device("cuda", 0)
+    tv = torch.from_numpy(vol).to(dev)[None, None]
+    i = torch.arange(w, dtype=torch.float32, device=dev) / w            # u = i / width   (kernel.cu:553-554)
+    j = torch.arange(h, dtype=torch.float32, device=dev) / h
+    U, Vv = torch.meshgrid(i, j, indexing="xy")                          # [j, i]
+    for orient, (dx, dy, dz) in ((vv.SAGITTAL, (0.01, -0.02, 0.37)), (vv.HORIZONTAL, (0.03, 0.41, 0.02)), (vv.CORONAL, (0.63, 0.0, -0.01))):
+        got = ctx.slice(h, w, dx, dy, dz, orientation=orient, filter=vv.FILTER_EXACT, fill=-1.0).reshape(w, h)   # element (j, i) at j*height + i
+        if orient == vv.SAGITTAL:
+            px, py, pz = U + dx, Vv + dy, torch.zeros_like(U) + dz        # kernel.cu:559-563
+        elif orient == vv.HORIZONTAL:
+            px, py, pz = Vv + dx, torch.zeros_like(U) + dy, U + dz        # :565-571
+        else:
+            px, py, pz = torch.zeros_like(U) + dx, Vv + dy, U + dz        # :573-579
+        grid = torch.stack([2 * px - 1, 2 * py - 1, 2 * pz - 1], dim=-1)[None, None]    # (x, y, z) order, [-1, 1]
+        ref = F.grid_sample(tv, grid, mode="bilinear", padding_mode="border", align_corners=False)[0, 0, 0]
+        inb = (px >= 0) & (px < 1) & (py >= 0) & (py < 1) & (pz >= 0) & (pz < 1)
+        ref = torch.where(inb, ref, torch.zeros_like(ref)).cpu().numpy()
+        d = np.abs(got[:h, :w] - ref)
+        assert d.max() <= 1e-6, (orient, float(d.max()))
+        assert inb.float().mean() > 0.3
+
+
+def test_c5_streamed_2048_phong(ctx):
+    """BASELINE config C5 on one GPU: a 2048^3 f32 volume (32 GiB) uploaded slab by slab from ONE pinned host buffer
+    (u8 slabs promoted on the device: vv_load_volume_stream_*), central-difference gradient + Phong, 1920x1080,
+    step 1/2048.  Full size, so properties rather than a whole oracle frame: (1) a slab-row band against the oracle
+    on the host copy -- a > 4 GiB volume WITH Phong; (2) the frame equals the reassembly of its 8 interleaved shards and
+    their sample counts add up; (3) determinism."""
+    import torch
+    n = 2048
+    dev = torch.device("cuda", 0)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    if free_b < 60 * 2 ** 30:
+        pytest.skip("needs 60 GiB of free HBM")
+    v8 = torch.empty(n ** 3, dtype=torch.uint8, device=dev)
+    ctx.generate_noise_device(v8.data_ptr(), n, n, n, 0x9E3779B9)
+    torch.cuda.synchronize()
+    host8 = np.empty((n, n, n), np.uint8)
+    per = 32                                                               # 128 MiB slabs
+    pin = torch.empty((per, n, n), dtype=torch.uint8).pin_memory()
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    v8v = v8.view(n, n, n)
+
+    def slabs():
+        for z0 in range(0, n, per):
+            pin.copy_(v8v[z0:z0 + per])                                    # device -> the one pinned buffer (stands in for a file reader)
+            host8[z0:z0 + per] = pin.numpy()
+            yield z0, pin.numpy()
+    ctx.load_volume_streamed(slabs(), vv.VOXEL_F32, n, n, n, tf)
+    del v8, v8v
+    torch.cuda.empty_cache()
+    W, H = 1920, 1080
+    cam = vv.Camera()
+    step = 1.0 / n
+    full = ctx.render(W, H, cam, phong=True, options=vv.make_options(step=step, count_samples=True), fill=0)
+    n_full = ctx.last_sample_count()
+    again = ctx.render(W, H, cam, phong=True, options=vv.make_options(step=step), fill=0)
+    assert np.array_equal(full, again)
+    assert (full[..., 3] > 0).mean() > 0.3
+    parts = np.zeros_like(full)
+    total = 0
+    for r in range(8):
+        ctx.render(W, H, cam, phong=True, options=vv.make_options(step=step, shard=(4, 8, r), count_samples=True), out=parts)
+        total += ctx.last_sample_count()
+    assert np.array_equal(parts, full) and total == n_full
+    band = (38, 39)                                                        # the slab row through the image centre
+    rows = slice(band[0] * 14, band[1] * 14)
+    host = np.empty((n, n, n), np.float32)
+    for z0 in range(0, n, 64):
+        host[z0:z0 + 64] = host8[z0:z0 + 64].astype(np.float32) / np.float32(255)     # == the device's promotion (v / 255.f)
+    del host8
+    want = np.zeros_like(full)
+    O.render(host, tf, W, H, cam, phong=True, options=vv.make_options(step=step, slab_rows=band), out=want,
+             threads=min(len(os.sched_getaffinity(0)), 16))
+    assert_frames_close(full[rows], want[rows], "C5 band (2048^3 f32, Phong)")
+    ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)                    # free the 32 GiB
 
 
 def test_noise_generator_matches_oracle(ctx):

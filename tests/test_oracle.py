@@ -46,9 +46,10 @@ def test_random_ellipsoids_hashes(golden_dir):
         assert sha(out) == hs[name]["sha256"], name
 
 
-@pytest.mark.skipif(O.ref() is None, reason="oracle/_ref not built (reference tree absent)")
 def test_generator_against_live_reference():
-    ref = O.ref()
+    ref = O.ref()          # (looked up here, not at collection: the GPU run never opens the compiled reference)
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
     for dims in ((48, 48, 48), (31, 17, 5), (1, 1, 1), (100, 3, 2)):
         nx, ny, nz = dims
         r = np.zeros((nz, ny, nx), np.uint8)

@@ -9,7 +9,8 @@ v8 = torch.empty(n**3, dtype=torch.uint8, device=dev); ctx.generate_noise_device
 ctx.load_volume_device(v8.data_ptr(), vv.VOXEL_U8, n, n, n, ramp_tf()); torch.cuda.synchronize()
 frame = torch.zeros((64, 64, 4), dtype=torch.uint8, device=dev)
 cam = vv.Camera(); o = vv.make_options(step=1/64, shard=(4, 8, 3))
-s = torch.cuda.current_stream().cuda_stream
+ts = torch.cuda.Stream(device=dev); torch.cuda.set_stream(ts)
+s = vv.stream_handle(ts)      # a caller stream: vv_render only enqueues
 for _ in range(20): ctx.render_device(64, 64, cam, frame.data_ptr(), options=o, stream=s)
 torch.cuda.synchronize()
 t = time.perf_counter()

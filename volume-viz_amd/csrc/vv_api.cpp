@@ -17,8 +17,27 @@
 
 using namespace vv;
 
+// Developer / experiment knobs (VV_* environment variables).  Read when the context is created and again at every
+// volume load -- never on the per-frame path.
+struct vv_knobs {
+    int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
+    int bricked = -1, zpair = -1, wstaged = 0, sweep = -1, sweep_trace = 0, force_big = 0;
+    int sw_nl = -1, sw_wx = -1, sw_wy = -1, sw_group = -1, sw_depth = -1, sw_lead = -1, sw_verbose = 0;
+    static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+    void read()
+    {
+        tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
+        lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
+        bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1); wstaged = geti("VV_WSTAGED", 0);
+        sw_nl = geti("VV_SWEEP_NL", -1); sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_group = geti("VV_SWEEP_GROUP", -1);
+        sw_depth = geti("VV_SWEEP_DEPTH", -1); sw_lead = geti("VV_SWEEP_LEAD", -1); sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
+        sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
+    }
+};
+
 struct vv_context {
     int device = 0;
+    vv_knobs knobs;
     hipStream_t stream = nullptr;          // used when the caller passes no stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -26,7 +45,7 @@ struct vv_context {
     void *d_vol = nullptr; size_t vol_bytes = 0; int vtype = VV_VOXEL_U8; int nx = 0, ny = 0, nz = 0;
     size_t row_pitch = 0, slice_pitch = 0, alloc_bytes = 0;   // linear layout in HBM (bytes); vol_bytes stays nx*ny*nz*voxel
     // bricked copy of an f32 volume for views off the memory axis (built on first use, dropped on reload)
-    void *d_bricks = nullptr; bool bricks_valid = false; uint32_t b_sy = 0, b_sz64 = 0; size_t bricks_bytes = 0;
+    void *d_bricks = nullptr; bool bricks_valid = false, bricks_failed = false; uint32_t b_sy = 0, b_sz64 = 0; size_t bricks_bytes = 0;
     // z-pair copy of an f32 volume for views along the memory axis (same life cycle)
     void *d_zpair = nullptr; bool zpair_valid = false; uint32_t zp_row = 0, zp_slab = 0; size_t zpair_bytes = 0;
     // transfer function
@@ -58,10 +77,19 @@ static int fail(vv_context *c, int code, const std::string &msg)
 #define HIPCHK(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
     return fail((c), VV_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
+// `stream` of the C-ABI: NULL = the context's own stream, the call returns when the work is done;
+// VV_STREAM_DEFAULT_ASYNC = the device's default (null) stream, enqueue only; anything else = that stream, enqueue only.
+static inline hipStream_t pick_stream(const vv_context *c, void *stream)
+{
+    if (!stream) return c->stream;
+    if (stream == VV_STREAM_DEFAULT_ASYNC) return (hipStream_t)0;
+    return (hipStream_t)stream;
+}
+
 static void drop_bricks(vv_context *c)
 {
     if (c->d_bricks) (void)hipFree(c->d_bricks);
-    c->d_bricks = nullptr; c->bricks_valid = false; c->bricks_bytes = 0;
+    c->d_bricks = nullptr; c->bricks_valid = false; c->bricks_failed = false; c->bricks_bytes = 0;
     if (c->d_zpair) (void)hipFree(c->d_zpair);
     c->d_zpair = nullptr; c->zpair_valid = false; c->zpair_bytes = 0;
 }
@@ -96,6 +124,7 @@ int vv_init(int device, vv_context **out)
     if (device >= count) return fail(nullptr, VV_ERR_INVALID, "vv_init: device index out of range");
     vv_context *c = new vv_context();
     c->device = device;
+    c->knobs.read();
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc((void **)&c->d_counter, 16 * sizeof(unsigned long long)) != hipSuccess ||
@@ -164,13 +193,14 @@ static int install_volume(vv_context *c, const void *src, bool src_on_device, in
     if ((size_t)nx * vsz >= (1u << 24) || nx >= (1 << 24) || ny >= (1 << 24) || nz >= (1 << 24))
         return fail(c, VV_ERR_INVALID, "load_volume: a volume row must be below 16 MiB and each dimension below 2^24");
     HIPCHK(c, hipSetDevice(c->device));
+    c->knobs.read();
     // one slice + one row + 16 bytes of zero padding: weight-0 corner fetches of edge
     // samples land here instead of needing index clamps (see vv_device.h VolumeView)
     const size_t pad = (size_t)nx * ny * vsz + 2 * (size_t)nx * vsz + 4096;   // (the sweep's loaders read whole 128-byte cells: up to one more row + a cell)
     drop_bricks(c);
     if (c->d_vol) { HIPCHK(c, hipFree(c->d_vol)); c->d_vol = nullptr; }   // the reference leaks here
     HIPCHK(c, hipMalloc(&c->d_vol, bytes + pad));
-    hipStream_t st = s ? s : c->stream;
+    hipStream_t st = s ? (s == (hipStream_t)VV_STREAM_DEFAULT_ASYNC ? (hipStream_t)0 : s) : c->stream;
     HIPCHK(c, hipMemsetAsync((char *)c->d_vol + bytes, 0, pad, st));
     if (src_on_device) HIPCHK(c, hipMemcpyAsync(c->d_vol, src, bytes, hipMemcpyDeviceToDevice, st));
     else { HIPCHK(c, hipMemcpyAsync(c->d_vol, src, bytes, hipMemcpyHostToDevice, st)); }
@@ -205,11 +235,18 @@ int vv_prepare_layouts(vv_context *c, int which, void *stream)
     if (!c->d_vol) return fail(c, VV_ERR_NO_VOLUME, "vv_prepare_layouts: no volume loaded");
     if (which & ~(VV_LAYOUT_BRICKED | VV_LAYOUT_ZPAIR)) return fail(c, VV_ERR_INVALID, "vv_prepare_layouts: unknown layout bit");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = pick_stream(c, stream);
     int built = 0;
     if ((which & VV_LAYOUT_BRICKED) && ensure_bricks(c, st)) built |= VV_LAYOUT_BRICKED;
     if ((which & VV_LAYOUT_ZPAIR) && ensure_zpair(c, st)) built |= VV_LAYOUT_ZPAIR;
     return built;
+}
+
+int vv_reread_env(vv_context *c)
+{
+    if (!c) return VV_ERR_INVALID;
+    c->knobs.read();
+    return VV_OK;
 }
 
 int vv_debug_sweep_trace(vv_context *c, unsigned long long *out, int max_blocks)
@@ -252,6 +289,7 @@ int vv_load_volume_stream_begin(vv_context *c, int vtype, int nx, int ny, int nz
     if ((size_t)nx * vsz >= (1u << 24) || ny >= (1 << 24) || nz >= (1 << 24))
         return fail(c, VV_ERR_INVALID, "stream_begin: a volume row must be below 16 MiB and each dimension below 2^24");
     HIPCHK(c, hipSetDevice(c->device));
+    c->knobs.read();
     const size_t bytes = (size_t)nx * ny * nz * vsz, pad = (size_t)nx * ny * vsz + 2 * (size_t)nx * vsz + 4096;
     drop_bricks(c);
     if (c->d_vol) { HIPCHK(c, hipFree(c->d_vol)); c->d_vol = nullptr; }
@@ -302,6 +340,10 @@ int vv_load_volume_stream_slices(vv_context *c, const void *src, int src_type, i
             HIPCHK(c, hipGetLastError());
         }
         HIPCHK(c, hipEventRecord(c->pin_ev[b], c->copy_stream));
+        // A pinned source is read by the copy engine straight from the caller's buffer: do not return before that read is
+        // over, or a producer that refills the buffer would race it.  (Pageable sources were copied into our own staging
+        // buffer above; their transfer keeps overlapping the caller's next fill.)
+        if (pinned) HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));
         done += nv;
     }
     return VV_OK;
@@ -324,11 +366,11 @@ int vv_load_volume_t3d(vv_context *c, const char *path, int header, int vtype, c
     int nx, ny, nz;
     int rc = vv_t3d_read_header(path, header, &nx, &ny, &nz);
     if (rc) return fail(c, rc, "vv_load_volume_t3d: cannot read the header");
-    rc = vv_load_volume_stream_begin(c, vtype, nx, ny, nz, tf);
-    if (rc) return rc;
-    FILE *f = fopen(path, "rb");
+    FILE *f = fopen(path, "rb");                 // before the old volume is given up
     if (!f) return fail(c, VV_ERR_IO, "vv_load_volume_t3d: cannot open file");
     if (header && fseek(f, 24, SEEK_SET) != 0) { fclose(f); return fail(c, VV_ERR_IO, "vv_load_volume_t3d: seek failed"); }
+    rc = vv_load_volume_stream_begin(c, vtype, nx, ny, nz, tf);
+    if (rc) { fclose(f); return rc; }
     const size_t slice = (size_t)nx * ny;
     int per = (int)std::max<size_t>(1, (32u << 20) / slice);
     std::string buf;
@@ -345,8 +387,15 @@ int vv_load_volume_t3d(vv_context *c, const char *path, int header, int vtype, c
     }
     fclose(f);
     int r3 = vv_load_volume_stream_end(c);
-    if (rc == VV_ERR_IO) return fail(c, VV_ERR_IO, "vv_load_volume_t3d: file shorter than its header says");
-    return rc ? rc : r3;
+    if (rc || r3) {
+        // a partly filled volume must not be rendered: drop it, later calls report VV_ERR_NO_VOLUME
+        drop_bricks(c);
+        if (c->d_vol) { (void)hipFree(c->d_vol); c->d_vol = nullptr; }
+        c->nx = c->ny = c->nz = 0; c->vol_bytes = 0; c->streaming = false;
+        if (rc == VV_ERR_IO) return fail(c, VV_ERR_IO, "vv_load_volume_t3d: file shorter than its header says");
+        return rc ? rc : r3;
+    }
+    return VV_OK;
 }
 
 int vv_volume_dims(const vv_context *c, int dims[3], int *vtype)
@@ -400,12 +449,13 @@ static int finalize_layout(vv_context *c, hipStream_t st)
 static bool ensure_bricks(vv_context *c, hipStream_t st)
 {
     if (c->bricks_valid) return true;
+    if (c->bricks_failed) return false;                                   // (until the next volume load)
     uint32_t sy = 0, sz64 = 0;
     const size_t bb = brick_copy_bytes(c->vtype, c->nx, c->ny, c->nz, &sy, &sz64);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bb + (512ull << 20) || sz64 >= (1u << 24) ||
-        hipMalloc(&c->d_bricks, bb + 16) != hipSuccess) {
-        (void)hipGetLastError(); c->d_bricks = nullptr;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bb + (512ull << 20) || sz64 >= (1u << 24) || sy >= (1u << 24) ||
+        hipMalloc(&c->d_bricks, bb + 16) != hipSuccess) {                  // (the sampler multiplies b_sy and b_sz64 as 24-bit values)
+        (void)hipGetLastError(); c->d_bricks = nullptr; c->bricks_failed = true;
         return false;                                                     // no room: linear path
     }
     launch_build_bricks(c->vtype, c->d_vol, c->row_pitch, c->slice_pitch, c->d_bricks, c->nx, c->ny, c->nz, st);
@@ -448,7 +498,7 @@ static VolumeView view_of(const vv_context *c)
     (void)vsz;
     V.row_bytes = (uint32_t)c->row_pitch;
     V.slice_bytes = (uint32_t)c->slice_pitch;
-    V.big = c->slice_pitch * (size_t)c->nz > (1ull << 32) || V.slice_bytes >= (1u << 24) || getenv("VV_FORCE_BIG") != nullptr;
+    V.big = c->slice_pitch * (size_t)c->nz > (1ull << 32) || V.slice_bytes >= (1u << 24) || c->knobs.force_big;
     V.bricks = nullptr; V.b_sy = 0; V.b_sz64 = 0;
     V.zpair = nullptr; V.zp_row_bytes = 0; V.zp_slab_bytes = 0;
     return V;
@@ -501,7 +551,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         if (!(cam->scale[a] > 0.f) || !std::isfinite(cam->scale[a]))
             return fail(c, VV_ERR_INVALID, "vv_render: camera scale must be finite and > 0");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = pick_stream(c, stream);
 
     MarchArgs A;
     memset(&A, 0, sizeof A);
@@ -595,7 +645,8 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         const float ax = fabsf(P.side[0]) , ay = fabsf(P.side[1]), az = fabsf(P.side[2]);
         if (ax >= 0.97f * sqrtf(ax * ax + ay * ay + az * az)) A.strips.tile_log2w = 5;
     }
-    if (const char *e = getenv("VV_TILE_LOG2W")) { int t = atoi(e); if (t >= 3 && t <= 5) A.strips.tile_log2w = t; }
+    const vv_knobs &K = c->knobs;
+    if (K.tile_log2w >= 3 && K.tile_log2w <= 5) A.strips.tile_log2w = K.tile_log2w;
     // Occupancy cap + gathers in flight (speed only; measured on MI355X):
     //   volume beyond the caches (> 1 GiB), aligned view : 2 blocks per CU, 3 samples per trip
     //   volume beyond the caches, rotated, linear layout : 1 block  per CU, 3 samples per trip
@@ -605,7 +656,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // XCD-aware block order: XCD k renders strips k, k+8, ... (each a full-width row of tiles), so
     // the tiles that share volume cache lines share an L2 (measured: -4 % on every workload)
     A.strips.xcd_band = 1;
-    if (const char *e = getenv("VV_XCD_BAND")) { int t = atoi(e); if (t >= 0 && t <= 64) A.strips.xcd_band = t; }
+    if (K.xcd_band >= 0 && K.xcd_band <= 64) A.strips.xcd_band = K.xcd_band;
     const bool beyond_caches = c->vol_bytes > (1ull << 30);
     // Sampling density: voxels of volume per sample = (voxels per step) x (voxels per pixel)^2 at the
     // cube centre.  Sparse rays (C3 at 1080p: 4.9) reuse little of a cache line and want few waves on a CU's
@@ -626,21 +677,22 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     A.unroll = (A.strips.tile_log2w == 5 || beyond_caches) ? 3 : 2;
     // (re-swept with tools/ab_reserve.sh at the end of round 1: 4 blocks per CU for volumes up to 1 GiB)
     A.lds_reserve = !beyond_caches ? 36000 : (A.strips.tile_log2w == 5 ? big_reserve : 155000);
-    if (const char *e = getenv("VV_UNROLL")) { int t = atoi(e); if (t == 2 || t == 3) A.unroll = t; }
-    if (const char *e = getenv("VV_LDS_RESERVE")) { int t = atoi(e); if (t >= 0 && t <= 155 * 1024) A.lds_reserve = t; }
+    const bool k_unroll = K.unroll == 2 || K.unroll == 3, k_reserve = K.lds_reserve >= 0 && K.lds_reserve <= 155 * 1024;
+    if (k_unroll) A.unroll = K.unroll;
+    if (k_reserve) A.lds_reserve = K.lds_reserve;
     // Bricked copy (speed only): off the memory axis the linear layout costs one cache line per lane
     // and gather; 4x4x4 bricks keep a wave's footprint in a few dozen lines.  both voxel types, both kernels;
     // built on first use if HBM has room (1.25x an f32 volume, 2x a u8 volume).  VV_BRICKED=0/1 overrides the policy.
     // Measured: 1024^3 rotated 3.85 -> 1.65 ms (f32), 3.17 -> 0.99 ms (u8); C2 (256^3) -19 %, C1 (128^3) -9 %;
     // only volumes far below the frame's sampling density lose (64^3 at 1080p, step 1/512: +10 %).
     bool use_bricks = A.strips.tile_log2w == 3 && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
-    if (const char *e = getenv("VV_BRICKED")) use_bricks = atoi(e) != 0;
+    if (K.bricked >= 0) use_bricks = K.bricked != 0;
     if (use_bricks) use_bricks = ensure_bricks(c, st);
     if (use_bricks) {
         A.V.bricks = c->d_bricks; A.V.b_sy = c->b_sy; A.V.b_sz64 = c->b_sz64;
         // measured (C3 rotated, 1024^3): 2 blocks per CU and 2 samples per trip: 3.64 -> 1.60 ms
-        if (!getenv("VV_UNROLL")) A.unroll = 2;
-        if (!getenv("VV_LDS_RESERVE")) A.lds_reserve = beyond_caches ? big_reserve : 36000;
+        if (!k_unroll) A.unroll = 2;
+        if (!k_reserve) A.lds_reserve = beyond_caches ? big_reserve : 36000;
     }
     // z-pair copy (speed only): along the memory axis the four corners (x..x+1, z..z+1) of a row come
     // from one gather (16 bytes for f32, 4 for u8), so a sample costs 2 gathers instead of 4 (f32) or 8
@@ -651,14 +703,14 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     //   Phong path: 0...-3 %: not used.                                  VV_ZPAIR=0/1 overrides.
     bool use_zpair = !use_bricks && A.strips.tile_log2w == 5 && !shading->phongShading &&
                      (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20));
-    if (const char *e = getenv("VV_ZPAIR")) use_zpair = atoi(e) != 0 && !use_bricks;
+    if (K.zpair >= 0) use_zpair = K.zpair != 0 && !use_bricks;
     if (use_zpair) use_zpair = ensure_zpair(c, st);
     if (use_zpair) { A.V.zpair = c->d_zpair; A.V.zp_row_bytes = c->zp_row; A.V.zp_slab_bytes = c->zp_slab; }
     // Phong kernel: 14.3 KB of LDS per block + this reserve.  Measured (tools/ab_phong.sh): volumes up to
     // 1 GiB like 5 blocks per CU (C2 0.54 -> 0.47 ms against no cap, u8 1024^3 1.88 -> 1.78), the 4 GiB
     // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)
     A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f) ? 30000 : 13000);
-    if (const char *e = getenv("VV_LDS_RESERVE_PHONG")) { int t = atoi(e); if (t >= 0 && t <= 146 * 1024) A.lds_reserve_phong = t; }
+    if (K.lds_reserve_phong >= 0 && K.lds_reserve_phong <= 146 * 1024) A.lds_reserve_phong = K.lds_reserve_phong;
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
     int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));
@@ -668,12 +720,15 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
 
     const size_t fb = (size_t)W * H * 4;
     uint8_t *d_out = rgba_out;
+    // Pixels the frame does not write (column W-1, row H-1, rows of other shards) must keep the caller's bytes.  A whole
+    // frame is read back as the (W-1) x (H-1) rectangle it writes; a sharded / row-limited frame goes through a staged
+    // copy of the caller's buffer (rare path).
+    const bool whole = s_count <= 1 && rb == 0 && re == P.nby && W >= 2 && H >= 2;
     if (!out_on_device) {
         rc = ensure(c, (void **)&c->d_frame, &c->frame_cap, fb);
         if (rc) return rc;
         d_out = c->d_frame;
-        // untouched pixels must keep the caller's bytes: stage the caller's frame first
-        HIPCHK(c, hipMemcpyAsync(d_out, rgba_out, fb, hipMemcpyHostToDevice, st));
+        if (!whole) HIPCHK(c, hipMemcpyAsync(d_out, rgba_out, fb, hipMemcpyHostToDevice, st));
     }
     A.pixels = (uint32_t *)d_out;
     if (((uintptr_t)d_out & 3) != 0) return fail(c, VV_ERR_INVALID, "vv_render: output buffer must be 4-byte aligned");
@@ -690,16 +745,18 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         // view: 8.8 ms vs 6.8 ms), so it is opt-in (VV_WSTAGED=1) and kept as the base for the
         // staged design of DESIGN.md section 4.  It needs 16-byte aligned rows and <= 4 GiB.
         bool wst = false;
-        if (const char *e = getenv("VV_WSTAGED")) wst = atoi(e) != 0 && (A.V.row_bytes % 16u) == 0 && !A.V.big;
+        if (K.wstaged) wst = (A.V.row_bytes % 16u) == 0 && !A.V.big;
         // Slab sweep (vv_sweep.hip): the volume streamed through LDS by dedicated loader waves.
         bool sweep = false;
-        if (const char *e = getenv("VV_SWEEP")) sweep = atoi(e) != 0;
+        if (K.sweep >= 0) sweep = K.sweep != 0;
         if (sweep && !wst) {
             const int own_bands = s_count > 1 ? A.strips.n_strips / A.strips.strips_per_band : 0;
+            A.sweep.nl = K.sw_nl; A.sweep.wx = K.sw_wx; A.sweep.wy = K.sw_wy; A.sweep.group = K.sw_group; A.sweep.depth = K.sw_depth;
+            A.sweep.lead = K.sw_lead; A.sweep.verbose = K.sw_verbose;
             plan_sweep(A, A.strips.y0, A.strips.n_strips * 8, own_bands);
             sweep = A.sweep.enabled != 0;
         }
-        if (sweep && !wst && getenv("VV_SWEEP_TRACE")) {
+        if (sweep && !wst && K.sweep_trace) {
             const int nb = ((A.sweep.nty + 7) / 8) * 8 * A.sweep.ntx;
             if (!c->d_trace) { if (hipMalloc((void **)&c->d_trace, 8ull * 8 * 65536) != hipSuccess) c->d_trace = nullptr; }
             if (c->d_trace && nb <= 65536) { HIPCHK(c, hipMemsetAsync(c->d_trace, 0, 64ull * nb, st)); A.sweep.trace = c->d_trace; c->trace_blocks = nb; }
@@ -715,7 +772,8 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     HIPCHK(c, hipGetLastError());
     c->timed = true;
     if (!out_on_device) {
-        HIPCHK(c, hipMemcpyAsync(rgba_out, d_out, fb, hipMemcpyDeviceToHost, st));
+        if (whole) HIPCHK(c, hipMemcpy2DAsync(rgba_out, (size_t)W * 4, d_out, (size_t)W * 4, (size_t)(W - 1) * 4, (size_t)(H - 1), hipMemcpyDeviceToHost, st));
+        else HIPCHK(c, hipMemcpyAsync(rgba_out, d_out, fb, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
     } else if (!stream) {
         HIPCHK(c, hipStreamSynchronize(st));
@@ -733,7 +791,7 @@ int vv_first_pass(vv_context *c, int W, int H, const camera_params *cam, const v
     for (int a = 0; a < 3; ++a)
         if (!(cam->scale[a] > 0.f) || !std::isfinite(cam->scale[a])) return fail(c, VV_ERR_INVALID, "vv_first_pass: camera scale must be finite and > 0");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = pick_stream(c, stream);
     FrameParams P;
     memset(&P, 0, sizeof P);
     P.W = W; P.H = H;
@@ -786,7 +844,7 @@ static int run_slice(vv_context *c, SliceArgs &S, float *buffer, int out_on_devi
     if (S.height < 1 || S.width < 1 || S.height > 65535u * 16 || S.width > 65535u * 16)
         return fail(c, VV_ERR_INVALID, "vv_slice: bad buffer size");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = pick_stream(c, stream);
     const size_t bytes = S.height * S.width * sizeof(float);
     S.V = view_of(c); S.V_type = c->vtype;
     float *d = buffer;
@@ -854,7 +912,7 @@ static int generate_impl(vv_context *c, uint8_t *out, int out_on_device, int nx,
     if (!out || nx < 1 || ny < 1 || nz < 1 || n < 0 || n > kMaxEllipsoids || (n > 0 && (!centers || !axes || !colors)))
         return fail(c, VV_ERR_INVALID, "vv_generate_ellipsoids: bad argument (n <= 64)");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = pick_stream(c, stream);
     const size_t bytes = (size_t)nx * ny * nz;
     uint8_t *d = out;
     void *tmp = nullptr;
@@ -897,7 +955,7 @@ int vv_promote_u8_to_f32(vv_context *c, const uint8_t *dev_in, float *dev_out, s
     if (!c || !dev_in || !dev_out) return fail(c, VV_ERR_INVALID, "vv_promote_u8_to_f32: NULL argument");
     if (((uintptr_t)dev_in & 15) || ((uintptr_t)dev_out & 15)) return fail(c, VV_ERR_INVALID, "vv_promote_u8_to_f32: buffers must be 16-byte aligned");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = pick_stream(c, stream);
     launch_promote_u8_f32(dev_in, dev_out, n, st);
     HIPCHK(c, hipGetLastError());
     if (!stream) HIPCHK(c, hipStreamSynchronize(st));
@@ -908,7 +966,7 @@ int vv_generate_noise_u8(vv_context *c, uint8_t *dev_out, int nx, int ny, int nz
 {
     if (!c || !dev_out || nx < 1 || ny < 1 || nz < 1) return fail(c, VV_ERR_INVALID, "vv_generate_noise_u8: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t st = pick_stream(c, stream);
     launch_noise_u8(dev_out, nx, ny, nz, seed, st);
     HIPCHK(c, hipGetLastError());
     if (!stream) HIPCHK(c, hipStreamSynchronize(st));

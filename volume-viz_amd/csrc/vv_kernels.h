@@ -14,6 +14,7 @@ struct SlabMap  { int r0, band, band_stride, n_regular; };
 // contiguous in both cases).
 struct SweepArgs {
     int enabled;
+    int verbose;           // print the planner's decision (VV_SWEEP_VERBOSE)
     int major;             // 1: slices are x-z planes (sweep along y); 2: x-y planes (sweep along z)
     int sgn;               // +1: slice index grows along every ray, -1: it falls
     int wx, wy, nc, nl;    // consumer waves across / down the tile, their product, loader waves per block

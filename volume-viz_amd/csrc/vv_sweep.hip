@@ -681,7 +681,8 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     using namespace sweepk;
     SweepArgs &S = A.sweep;
     S.enabled = 0;
-    const bool verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
+    const SweepArgs req = S;                   // requested values (developer knobs, read by vv_api.cpp at init / volume load; -1 = default)
+    const bool verbose = req.verbose != 0;
 #define VV_NO(why) do { if (verbose) fprintf(stderr, "sweep: not used (%s)\n", why); return; } while (0)
     const FrameParams &P = A.P;
     const VolumeView &V = A.V;
@@ -728,18 +729,18 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     S.major = best; S.sgn = best_sgn;
     // tile shape: wx x wy waves of 32 x 2 pixels.  Wide and short, so that a slice's image has few, long rows
     // (one LDS-DMA instruction per row) and the rim the neighbours re-read is small.
-    S.nl = 2; S.wx = 3; S.wy = 4;
-    if (const char *e = getenv("VV_SWEEP_NL")) { int t = atoi(e); if (t >= 1 && t <= 4) S.nl = t; }
-    if (const char *e = getenv("VV_SWEEP_WX")) { int t = atoi(e); if (t >= 1 && t <= 8) S.wx = t; }
-    if (const char *e = getenv("VV_SWEEP_WY")) { int t = atoi(e); if (t >= 1 && t <= 14) S.wy = t; }
-    S.group = 4;                             // slices per allocation / confirmation unit of the loaders
-    if (const char *e = getenv("VV_SWEEP_GROUP")) { int t = atoi(e); if (t >= 1 && t <= 8) S.group = t; }
+    S.nl = 3; S.wx = 3; S.wy = 4;
+    if (req.nl >= 1 && req.nl <= 4) S.nl = req.nl;
+    if (req.wx >= 1 && req.wx <= 8) S.wx = req.wx;
+    if (req.wy >= 1 && req.wy <= 14) S.wy = req.wy;
+    S.group = 3;                             // slices per allocation / confirmation unit of the loaders
+    if (req.group >= 1 && req.group <= 8) S.group = req.group;
     S.depth = 2;                             // groups a loader wave keeps pending before it waits for the oldest
-    if (const char *e = getenv("VV_SWEEP_DEPTH")) { int t = atoi(e); if (t >= 1 && t <= 8) S.depth = t; }
+    if (req.depth >= 1 && req.depth <= 8) S.depth = req.depth;
     S.lead = 0;                              // slices the prefetch wave runs ahead of the landed ones (0: no prefetch wave)
-    if (const char *e = getenv("VV_SWEEP_LEAD")) { int t = atoi(e); if (t >= 0 && t <= 64) S.lead = t; }
+    if (req.lead >= 0 && req.lead <= 64) S.lead = req.lead;
     if (S.wx * S.wy + S.nl + (S.lead > 0 ? 1 : 0) > 16) VV_NO("too many waves");
-    const bool forced = getenv("VV_SWEEP_WX") || getenv("VV_SWEEP_WY");
+    const bool forced = req.wx >= 1 || req.wy >= 1;
     for (;;) {
         S.nc = S.wx * S.wy;
         const int tw = 32 * S.wx, th = 2 * S.wy;

@@ -4,8 +4,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <fstream>
-#include <sstream>
 
 namespace {
 vv_context *g_ctx = nullptr;
@@ -33,7 +31,8 @@ extern "C" void registerCudaResources(unsigned, unsigned, unsigned)
 {
     // GL interop is wired by the host application; this headless build has
     // no GL context to register against.
-    fprintf(stderr, "registerCudaResources: built without GL interop; use registerHostResources()\n");
+    fprintf(stderr, "registerCudaResources: this is the headless build; link libvolviz_host_gl.so (registerCudaResourcesGL / runCudaGL, "
+                    "kernel_hip_gl.cpp) in a GL host, or use registerHostResources()\n");
     exit(EXIT_FAILURE);
 }
 
@@ -105,28 +104,6 @@ void VolumeGenerator::drawDefaultBrain()
         for (int li = 0; li < 4; li++)
             drawEllipsoid(Point3(centers[ci][0], centers[ci][1], centers[ci][2]),
                           Vector3(layers[li][0], layers[li][1], layers[li][2]), shades[li]);
-}
-
-std::string VolumeGenerator::volume2csv()
-{
-    std::ostringstream os;
-    for (int k = 0; k < m_z; k++) {
-        for (int j = 0; j < m_y; j++) {
-            for (int i = 0; i < m_x; i++) {
-                int offset = k * m_z * m_y + j * m_y + i;       // volumegenerator.cpp:128 (sic: z,y strides)
-                os << (int)m_volume[offset] << ",";
-            }
-            os << "\t";
-        }
-        os << "\n";
-    }
-    return os.str();
-}
-
-void VolumeGenerator::saveas_csv(char *path)
-{
-    std::ofstream dest(path, std::ios::out | std::ios::trunc);
-    dest << volume2csv();
 }
 
 void VolumeGenerator::saveas_raw(char *dest, bool header)

@@ -20,8 +20,7 @@ public:
     void drawEllipsoid(const Point3 &center, const Vector3 &axes, const byte &color);   // :31-97
     void drawDefaultBrain();                                                              // :100-119
 
-    std::string volume2csv();                       // :122-136 (keeps the reference's index quirk)
-    void saveas_csv(char *path);                    // :139-145
+    // (volume2csv / saveas_csv, volumegenerator.cpp:122-145: a debugging dump outside the hot path, not mirrored)
     void saveas_raw(char *dest, bool header = false);            // :147-174
     void loadfrom_raw(const char *source, bool header = false);  // :176-220
 

@@ -30,6 +30,16 @@ FILTER_TEX8, FILTER_EXACT = 0, 1
 ERT_REFERENCE, ERT_TRUE = 0, 1
 RAYS_IMAGES, RAYS_ANALYTIC = 0, 1
 TF_ENGINE, TF_HEAD, TF_MRI = 0, 1, 2
+# `stream` arguments: 0/None = the context's own stream, synchronous; STREAM_DEFAULT_ASYNC = the device's default (null)
+# stream, enqueue only (include/volviz.h VV_STREAM_DEFAULT_ASYNC); any other hipStream_t handle = that stream, enqueue only
+STREAM_DEFAULT_ASYNC = 1
+
+
+def stream_handle(torch_stream) -> int:
+    """hipStream_t of a torch.cuda.Stream for the `stream` arguments (torch's default stream has handle 0, which the
+    C-ABI reads as 'no stream': it maps to STREAM_DEFAULT_ASYNC)."""
+    h = int(torch_stream.cuda_stream)
+    return h if h != 0 else STREAM_DEFAULT_ASYNC
 
 
 class slice_params(C.Structure):          # kernel.cuh:26-29
@@ -68,7 +78,7 @@ EXPORTS = [
     "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid", "vv_debug_counters",
     "vv_first_pass", "vv_cut_plane_canonical", "vv_cut_plane_to_slice_params", "vv_slice_to_bgra",
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
-    "vv_prepare_layouts", "vv_device_bytes", "vv_debug_sweep_trace",
+    "vv_prepare_layouts", "vv_device_bytes", "vv_debug_sweep_trace", "vv_reread_env",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
 ]
 
@@ -124,6 +134,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_cut_plane_drag.argtypes = [vp, vp, vp, i, i, i, i]
     lib.vv_debug_counters.argtypes = [vp, vp]
     lib.vv_debug_sweep_trace.argtypes = [vp, vp, i]
+    lib.vv_reread_env.argtypes = [vp]
     lib.vv_prepare_layouts.argtypes = [vp, i, vp]
     lib.vv_device_bytes.argtypes = [vp, vp]
     lib.vv_volume_dims.argtypes = [vp, C.POINTER(i * 3), C.POINTER(i)]
@@ -335,6 +346,10 @@ class Context:
         out = np.zeros(16, np.uint64)
         self._chk(self.lib.vv_debug_counters(self.h, out.ctypes.data))
         return out
+
+    def reread_env(self):
+        """vv_reread_env: pick up VV_* knobs changed since the last volume load."""
+        self._chk(self.lib.vv_reread_env(self.h))
 
     def sweep_trace(self, max_blocks: int = 65536):
         out = np.zeros((max_blocks, 8), np.uint64)
