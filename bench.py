@@ -41,6 +41,32 @@ def ramp_tf() -> np.ndarray:
     return tf.astype(np.float32).reshape(1024)
 
 
+def csrc_sha() -> str:
+    """Hash of the kernel / C-ABI sources: profiles/pmc_traffic.json carries the hash it was measured with, and a
+    traffic figure taken with other kernels is not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "volume-viz_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(key):
+    """HBM-side bytes per launch from the committed PMC passes (tools/pmc_traffic.py), or None (+ why)."""
+    pj = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not os.path.exists(pj):
+        return None, "no profiles/pmc_traffic.json"
+    try:
+        j = json.load(open(pj))
+    except Exception as e:
+        return None, f"unreadable: {e}"
+    if j.get("csrc_sha") != csrc_sha():
+        return None, f"stale: measured with csrc {j.get('csrc_sha')}, this tree is {csrc_sha()} (re-run tools/pmc_traffic.py)"
+    return j.get("entries", {}).get(key), None
+
+
 def workload(args, world):
     if args.config == "c3":
         n = 1024
@@ -163,20 +189,25 @@ def main():
 
     # ---- untimed instrumented pass: executed samples + bricks touched (byte model) ----
     nb = (n + BRICK - 1) // BRICK
-    bitmap = torch.zeros((nb * nb * nb + 31) // 32, dtype=torch.int32, device=dev)
-    iopts = vv.make_options(count_samples=True, touched_bricks=bitmap.data_ptr(), **base)
-    ctx.render_device(W, H, cam, frame.data_ptr(), options=iopts, stream=stream, phong=args.phong)
-    torch.cuda.synchronize()
-    samples = ctx.last_sample_count()
+    vbytes = 4 if args.voxel == "f32" else 1
+    rows_owned = len(sharding.owned_rows(H, world, rank))
+
+    def instrumented(camera, phong):
+        """(executed samples, algorithmic bytes of SURVEY 8d: B_frame) of one frame of this rank"""
+        bitmap = torch.zeros((nb * nb * nb + 31) // 32, dtype=torch.int32, device=dev)
+        io = vv.make_options(count_samples=True, touched_bricks=bitmap.data_ptr(), **base)
+        ctx.render_device(W, H, camera, frame.data_ptr(), options=io, stream=stream, phong=phong)
+        torch.cuda.synchronize()
+        ns = ctx.last_sample_count()
+        words = bitmap.cpu().numpy().view(np.uint32)
+        nbricks = int(np.unpackbits(words.view(np.uint8)).sum())
+        return ns, nbricks * BRICK ** 3 * vbytes + 4 * W * rows_owned + 4096
+
+    samples, bytes_rank = instrumented(cam, args.phong)
     if os.environ.get("VV_STATS"):      # developer statistics from a counters-only frame (no brick marking)
         ctx.render_device(W, H, cam, frame.data_ptr(), options=vv.make_options(count_samples=True, **base), stream=stream, phong=args.phong)
         torch.cuda.synchronize()
         print("stats", ctx.debug_counters().tolist(), "instrumented frame ms", ctx.last_frame_ms(), file=sys.stderr)
-    words = bitmap.cpu().numpy().view(np.uint32)
-    bricks = int(np.unpackbits(words.view(np.uint8)).sum())
-    rows_owned = len(sharding.owned_rows(H, world, rank))
-    vbytes = 4 if args.voxel == "f32" else 1
-    bytes_rank = bricks * BRICK ** 3 * vbytes + 4 * W * rows_owned + 4096     # SURVEY 8d B_frame
     rdev = torch.device("cpu") if share else dev
     tot = torch.tensor([samples, bytes_rank], dtype=torch.float64, device=rdev)
     if world > 1:
@@ -212,6 +243,14 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el[0])
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))    # rad + march kernels of this rank
+    kern_all = torch.tensor([kern_ms], dtype=torch.float64, device=rdev)
+    if world > 1:
+        gl = [torch.zeros_like(kern_all) for _ in range(world)]
+        dist.all_gather(gl, kern_all)
+        kern_ranks = [round(float(g[0]), 4) for g in gl]
+        backend, nranks = dist.get_backend(), dist.get_world_size()
+    else:
+        kern_ranks, backend, nranks = [round(kern_ms, 4)], None, 1
 
     if rank != 0:
         if world > 1:
@@ -224,13 +263,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = samples_all * args.steps / elapsed / 1e6
     achieved = bytes_rank / (kern_ms * 1e-3)
-    traffic = None
-    pj = os.path.join(REPO, "profiles", "pmc_traffic.json")
-    if os.path.exists(pj):
-        try:
-            traffic = None if args.orbit else json.load(open(pj)).get(f"{args.config}-{args.volume}-{args.tf}-{args.view}-n{world}")
-        except Exception:
-            traffic = None
+    key = f"{args.config}-{args.volume}-{args.tf}-{args.view}{'-phong' if args.phong else ''}-n{world}"
+    traffic, traffic_note = (None, "diagnostic camera") if args.orbit else measured_traffic(key)
     out = {
         "metric": "Msamples/s (rays x steps), 1024^3 f32 volume @1080p", "value": round(value, 1),
         "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -241,63 +275,83 @@ def main():
                    "volume": [n, n, n], "frame": [W, H], "steps_per_unit_length": steps,
                    "sharding": "single GPU" if world == 1 else f"bands of {sharding.BAND_PX} pixel rows round-robin over {world} GPUs, volume replicated, 1 RCCL gather/frame"},
         "executed_samples_per_frame": int(samples_all), "upper_bound_samples_WxHxS": W * H * steps,
-        "kernel_ms_rank0": round(kern_ms, 4),
-        "roofline": {"bound": "hbm", "kernel": "march_kernel (+rad_kernel)", "achieved": round(achieved / 1e9, 1),
+        "kernel_ms_rank0": round(kern_ms, 4), "kernel_ms_per_rank": kern_ranks,
+        "collective": None if world == 1 else {"backend": backend, "ranks": nranks, "per_frame": "1 gather of RGBA8 bands to rank 0"},
+        "roofline": {"bound": "hbm", "kernel": ("march_phong_kernel" if args.phong else "march_kernel (+rad_kernel)"), "achieved": round(achieved / 1e9, 1),
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
                      "traffic": traffic, "algorithmic_bytes_per_launch": int(bytes_rank),
                      "bytes_per_sample": round(bytes_rank / max(samples, 1), 3)},
     }
+    if traffic_note:
+        out["roofline"]["traffic_note"] = traffic_note
 
-    # Not part of `value`: the same workload seen from a direction off the memory axis (SURVEY 8d's
-    # second camera), where vv_render samples the bricked copy of the volume.
-    if world == 1 and args.config == "c3" and args.view == "a" and not args.orbit and not os.environ.get("VV_BENCH_NO_EXTRA"):
+    # Not part of `value`: the other shipped march kernels on the same workload, each with its own algorithmic bytes
+    # (instrumented, untimed pass) and roofline fraction: the camera off the memory axis (SURVEY 8d's second camera:
+    # vv_render samples the bricked copy) and the Phong-shaded frame (march_phong_kernel).
+    if world == 1 and args.config == "c3" and args.view == "a" and not args.orbit and not args.phong and not os.environ.get("VV_BENCH_NO_EXTRA"):
+        def timed(camera, phong, reps=10):
+            for _ in range(2):
+                ctx.render_device(W, H, camera, frame.data_ptr(), options=opts, stream=stream, phong=phong)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ctx.render_device(W, H, camera, frame.data_ptr(), options=opts, stream=stream, phong=phong)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
         cam_b = vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5)
-        ctx.render_device(W, H, cam_b, frame.data_ptr(), options=vv.make_options(count_samples=True, **base), stream=stream, phong=args.phong)
-        torch.cuda.synchronize()
-        samples_b = ctx.last_sample_count()
-        for _ in range(2):
-            ctx.render_device(W, H, cam_b, frame.data_ptr(), options=opts, stream=stream, phong=args.phong)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            ctx.render_device(W, H, cam_b, frame.data_ptr(), options=opts, stream=stream, phong=args.phong)
-        e1.record()
-        torch.cuda.synchronize()
-        ms_b = e0.elapsed_time(e1) / 10
-        out["rotated_view"] = {"camera": "orbit r=4, theta=60 deg, phi=36 deg", "ms_per_frame": round(ms_b, 4),
-                               "value": round(samples_b / ms_b / 1e3, 1), "unit": "Msamples/s",
-                               "executed_samples_per_frame": int(samples_b)}
+        for name, camera, phong, what, tkey in (
+                ("rotated_view", cam_b, False, "camera on the orbit r=4, theta=60 deg, phi=36 deg: march_kernel on the bricked copy", "c3-noise-ramp-b-n1"),
+                ("phong", cam, True, "view a with central-difference gradient + Phong: march_phong_kernel", "c3-noise-ramp-a-phong-n1")):
+            ns_x, by_x = instrumented(camera, phong)
+            ms_x = timed(camera, phong)
+            tr_x, note_x = measured_traffic(tkey)
+            out[name] = {"what": what, "ms_per_frame": round(ms_x, 4), "value": round(ns_x / ms_x / 1e3, 1), "unit": "Msamples/s",
+                         "executed_samples_per_frame": int(ns_x),
+                         "roofline": {"bound": "hbm", "achieved": round(by_x / (ms_x * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                      "frac": round(by_x / (ms_x * 1e-3) / HBM_PEAK, 4), "traffic": tr_x, "algorithmic_bytes_per_launch": int(by_x)}}
+            if note_x:
+                out[name]["roofline"]["traffic_note"] = note_x
 
     if want_cpu:
-        # the CPU restatement (oracle/vvo.c, OpenMP) on this box's host cores, same workload.
-        # The GPU box shares its host: 16 cores is the share of one GPU.
+        # The CPU restatement (oracle/vvo.c, OpenMP) on this box's host cores (the GPU box shares its host: 16 cores is
+        # the share of one GPU).  BASELINE.md section 3 asks for config C1: 128^3 drawDefaultBrain volume (u8, as the
+        # reference stores it), 512x512, step 1/128, Head transfer function, camera (0,0,-4); 1 thread and all threads.
         sys.path.insert(0, os.path.join(REPO, "tests"))
         import oracle_lib as O
         cores = int(os.environ.get("VV_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+        c1_vol = O.draw_default_brain(128, 128, 128)
+        c1_tf = vv.transfer_preset(vv.TF_HEAD)
+        c1_cam = vv.Camera()
+        budget = max(2.0, args.cpu_seconds * 0.5)
+        t = time.perf_counter(); sN = 0; reps = 0
+        while reps == 0 or (time.perf_counter() - t < budget and reps < 64):
+            sN += O.render(c1_vol, c1_tf, 512, 512, c1_cam, threads=cores)[1]; reps += 1
+        dt = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": round(sN / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                               "ms_per_frame": round(dt / reps * 1e3, 2),
+                               "sample": f"config C1: {reps} x the whole 512x512 frame of the 128^3 drawDefaultBrain volume, Head TF, step 1/128 "
+                                         f"({sN} samples in {dt:.1f} s; oracle/vvo.c, OpenMP, {cores} threads)"}
+        t = time.perf_counter()
+        s1 = O.render(c1_vol, c1_tf, 512, 512, c1_cam, threads=1)[1]
+        d1 = time.perf_counter() - t
+        out["cpu_baseline_1thread"] = {"value": round(s1 / d1 / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                       "ms_per_frame": round(d1 * 1e3, 1), "sample": f"config C1, one frame ({s1} samples in {d1:.1f} s)"}
+        # the same port on the bench workload itself (C3), a slab-row band sized to the remaining time
         nby = (H + 13) // 14
         mid = nby // 2
         cbase = {k: v for k, v in base.items() if k != "shard"}
         t = time.perf_counter()
-        _, s1 = O.render(host_vol, tf, W, H, cam, options=vv.make_options(slab_rows=(mid, mid + 1), **cbase), threads=cores)
+        O.render(host_vol, tf, W, H, cam, options=vv.make_options(slab_rows=(mid, mid + 1), **cbase), threads=cores)
         dt1 = time.perf_counter() - t
-        rows = int(max(1, min(nby, args.cpu_seconds / max(dt1, 1e-3))))
+        rows = int(max(1, min(nby, budget / max(dt1, 1e-3))))
         lo = max(0, min(nby - rows, mid - rows // 2))
-        copts = vv.make_options(slab_rows=(lo, lo + rows), **cbase)
         t = time.perf_counter()
-        sN, reps = 0, 0
-        while reps == 0 or (rows == nby and time.perf_counter() - t < args.cpu_seconds and reps < 32):
-            sN += O.render(host_vol, tf, W, H, cam, options=copts, threads=cores)[1]
-            reps += 1
+        sN = O.render(host_vol, tf, W, H, cam, options=vv.make_options(slab_rows=(lo, lo + rows), **cbase), threads=cores)[1]
         dt = time.perf_counter() - t
-        # single-thread rate on one centre slab row (BASELINE.md section 3 asks for 1 and nproc)
-        t1 = time.perf_counter()
-        _, s1t = O.render(host_vol, tf, W, H, cam, options=vv.make_options(slab_rows=(mid, mid + 1), **cbase), threads=1)
-        d1t = time.perf_counter() - t1
-        out["cpu_baseline_1thread"] = {"value": round(s1t / d1t / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
-                                       "sample": f"centre slab row ({s1t} samples in {d1t:.1f} s)"}
-        what = f"{reps} x the whole frame" if rows == nby else f"slab rows [{lo},{lo + rows}) of {nby} of the same frame"
-        out["cpu_baseline"] = {"value": round(sN / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                               "sample": f"{what} ({sN} samples in {dt:.1f} s; oracle/vvo.c, OpenMP, {cores} threads)"}
+        out["cpu_baseline_c3"] = {"value": round(sN / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                                  "sample": f"slab rows [{lo},{lo + rows}) of {nby} of the bench frame itself ({sN} samples in {dt:.1f} s)"}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

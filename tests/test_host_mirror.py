@@ -58,3 +58,37 @@ def test_host_demo_matches_oracle(tmp_path):
     # the .t3d the mirror wrote is what the reference's loader expects
     raw = open(tmp_path / "demo.t3d", "rb").read()
     assert np.frombuffer(raw[:24], "<u8").tolist() == [48, 40, 56] and raw[24:] == vol.tobytes()
+
+
+def test_native_library_symbols():
+    """CPU check: the optional native libraries export what their headers declare -- the GL-interop half of the
+    kernel.cuh mirror (kernel.cu:375-453 over hip_gl_interop.h; compiled here, run only by a GL host) and the
+    one-process multi-GPU entry points of include/volviz_mgpu.h."""
+    import re
+    lib = os.path.join(REPO, "volume-viz_amd", "lib")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(lib, "libvolviz_host_gl.so")]).decode()
+    for name in ("registerCudaResourcesGL", "runCudaGL", "unregisterCudaResourcesGL"):
+        assert f" T {name}\n" in out, name
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", os.path.join(lib, "libvolviz_host_gl.so")]).decode()
+    for name in ("hipGraphicsGLRegisterImage", "hipGraphicsGLRegisterBuffer", "hipGraphicsMapResources", "hipGraphicsResourceGetMappedPointer", "vv_render"):
+        assert name in und, name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(lib, "libvolviz_mgpu.so")]).decode()
+    hdr = open(os.path.join(REPO, "include", "volviz_mgpu.h")).read()
+    declared = set(re.findall(r"\b(vv_mgpu_\w+)\s*\(", hdr))
+    assert len(declared) >= 10
+    for name in declared:
+        assert f" T {name}\n" in out, name
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", os.path.join(lib, "libvolviz_mgpu.so")]).decode()
+    for name in ("ncclCommInitAll", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd"):
+        assert name in und, name
+
+
+@pytest.mark.gpu
+def test_native_multi_gpu_entry_points_on_the_visible_gpus():
+    """bin/mgpu_demo: vv_mgpu_init on every visible GPU (one on the test box: the gather degenerates, the per-device
+    contexts, the on-device volume generation, streams and the host staging are exercised), frame identical to
+    vv_render's.  With more GPUs visible the same binary checks the RCCL gather."""
+    demo = os.path.join(REPO, "volume-viz_amd", "bin", "mgpu_demo")
+    r = subprocess.run([demo, "0", "96", "400", "300"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 differing bytes" in r.stdout, r.stdout
