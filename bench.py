@@ -265,6 +265,8 @@ def main():
     achieved = bytes_rank / (kern_ms * 1e-3)
     key = f"{args.config}-{args.volume}-{args.tf}-{args.view}{'-phong' if args.phong else ''}-n{world}"
     traffic, traffic_note = (None, "diagnostic camera") if args.orbit else measured_traffic(key)
+    if traffic is None and traffic_note is None:
+        traffic_note = f"no PMC passes committed for {key}"
     out = {
         "metric": "Msamples/s (rays x steps), 1024^3 f32 volume @1080p", "value": round(value, 1),
         "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

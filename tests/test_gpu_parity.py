@@ -485,6 +485,34 @@ def test_sweep_kernel_is_bit_identical(ctx, view, monkeypatch):
         assert n_got == n
 
 
+@pytest.mark.parametrize("spb", [2, 4])
+def test_phong_blocks_of_several_slabs_are_bit_identical(ctx, spb, monkeypatch):
+    """march_phong_kernel with 2 or 4 x-adjacent slabs per block (each slab keeps its own apron, radius and sample
+    cache; speed only): the sweep's cases with Phong forced on, frame widths that leave ghost slabs at the row's end,
+    W == 1 (mod 14), shards, every layout -- same frames, same sample counts."""
+    monkeypatch.setenv("VV_PHONG_SPB", str(spb))
+    for seed in range(0, 48, 5):
+        vol, tf, W, H, cam, sp, _, o = _random_case(seed)
+        ctx.load_volume(vol, tf)
+        opts = vv.make_options(**o)
+        got = ctx.render(W, H, cam, slice=sp, phong=True, options=opts, fill=0x3C)
+        n_got = ctx.last_sample_count()
+        want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=True, options=opts, fill=0x3C)
+        assert_frames_close(got, want, f"phong spb={spb} seed {seed}: {vol.shape} {vol.dtype} {W}x{H}")
+        assert n_got == n
+    vol = O.draw_default_brain(64, 64, 64)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    for W, H, shard in ((170, 170, None), (43, 57, None), (300, 200, (4, 3, 1)), (15, 16, None)):
+        o = vv.make_options(count_samples=True, shard=shard)
+        for cam in (_cam("a"), _cam("b")):
+            got = ctx.render(W, H, cam, phong=True, options=o, fill=7)
+            n_got = ctx.last_sample_count()
+            want, n = O.render(vol, tf, W, H, cam, phong=True, options=o, fill=7)
+            assert_frames_close(got, want, f"phong spb={spb} {W}x{H} shard={shard}")
+            assert n_got == n
+
+
 @pytest.mark.parametrize("seed", range(0, 48, 3))
 def test_bricked_copy_is_bit_identical(ctx, seed, monkeypatch):
     """The 4x4x4-brick copy of the volume (used by default for views off the memory axis on volumes

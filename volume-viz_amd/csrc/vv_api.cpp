@@ -22,6 +22,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, wstaged = 0, sweep = -1, sweep_trace = 0, force_big = 0;
+    int phong_spb = -1;
     int sw_nl = -1, sw_wx = -1, sw_wy = -1, sw_group = -1, sw_depth = -1, sw_lead = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
@@ -29,6 +30,7 @@ struct vv_knobs {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1); wstaged = geti("VV_WSTAGED", 0);
+        phong_spb = geti("VV_PHONG_SPB", -1);
         sw_nl = geti("VV_SWEEP_NL", -1); sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_group = geti("VV_SWEEP_GROUP", -1);
         sw_depth = geti("VV_SWEEP_DEPTH", -1); sw_lead = geti("VV_SWEEP_LEAD", -1); sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
@@ -711,6 +713,8 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)
     A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f) ? 30000 : 13000);
     if (K.lds_reserve_phong >= 0 && K.lds_reserve_phong <= 146 * 1024) A.lds_reserve_phong = K.lds_reserve_phong;
+    A.phong_spb = 1;
+    if (K.phong_spb == 1 || K.phong_spb == 2 || K.phong_spb == 4) A.phong_spb = K.phong_spb;
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
     int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));

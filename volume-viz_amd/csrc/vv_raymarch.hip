@@ -291,31 +291,41 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 // thread keeps marching its own chunk sequence until the whole block is done, so
 // neighbour entries are never stale (pin 5).
 // ---------------------------------------------------------------------------
-template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
-__global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeView V,
+// SPB x-adjacent slabs per block (256 threads each, own apron, own `rad`, own LDS cache): a slab's footprint is 16
+// pixels wide, about one 128-byte line of voxels that mostly straddles two; neighbouring slabs marched by the same
+// block at the same time find each other's lines in L1 (measured: the one-slab form moves 2.8x the algorithmic bytes).
+template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB>
+__global__ __launch_bounds__(256 * SPB) void march_phong_kernel(FrameParams P, VolumeView V,
                                                           const float4 *__restrict__ tf, SlabMap M,
                                                           uint32_t *__restrict__ pixels,
                                                           unsigned long long *__restrict__ counter,
                                                           uint32_t *__restrict__ bricks)
 {
     __shared__ float4 lds_tf[256];
-    __shared__ float red[256];
-    __shared__ uint8_t cache[kCacheDepth][256];
+    __shared__ float red_[SPB][256];
+    __shared__ uint8_t cache_[SPB][kCacheDepth][256];
     __shared__ float q255[256];              // q / 255.f for every byte q, by the same IEEE division
     __shared__ int any_live;
+    const int tid = threadIdx.x & 255, sub = threadIdx.x >> 8;
+    float *red = red_[sub];
+    uint8_t (*cache)[256] = cache_[sub];
     // XCD-aware order (speed only, as in march_kernel): linear block L runs on XCD L % 8; XCD k takes the
     // grid rows k, k+8, ... so that the slabs of one row, which share volume lines, share an L2
-    const int gx = ((int)blockIdx.x >> 3) % P.nbx, gy = (((int)blockIdx.x >> 3) / P.nbx) * 8 + ((int)blockIdx.x & 7);
+    const int nbxg = (P.nbx + SPB - 1) / SPB;
+    const int gx = ((int)blockIdx.x >> 3) % nbxg, gy = (((int)blockIdx.x >> 3) / nbxg) * 8 + ((int)blockIdx.x & 7);
     if (gy > M.n_regular) return;                              // block-uniform, before any barrier
     stage_tf(lds_tf, tf);
     // kernel.cu:175-177 divides six cached bytes by 255.f per shaded sample; a correctly rounded
     // division is ~10 instructions, a table look-up of the same quotient is one LDS read
-    q255[threadIdx.x] = (float)threadIdx.x / 255.f;      // visible after the barriers of the reduction below
+    if (sub == 0) q255[tid] = (float)tid / 255.f;        // visible after the barriers of the reduction below
 
     // grid row gy -> slab row of this shard; the last grid row is the "extra" slab row
     // nby-1 that re-writes pixel row H-2 when H == 1 (mod 14) (pin 10): it travels with
     // the shard that owns pixel row H-2.
-    const int bx = gx;
+    // the block's slabs gx*SPB .. gx*SPB+SPB-1 of the slab row; one beyond the row's end marches a ghost copy of the
+    // last slab (it keeps the barriers in step) and writes nothing
+    const bool ghost = gx * SPB + sub >= P.nbx;
+    const int bx = ghost ? P.nbx - 1 : gx * SPB + sub;
     int by;
     if (gy == M.n_regular) { if (!P.conflict_y) return; by = P.nby - 1; }
     else by = M.r0 + (gy / M.band) * M.band_stride + (gy % M.band);
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
         int yrow = (P.conflict_y && by == P.nby - 1) ? P.H - 2 : by * kSlab;
         if (yrow > (P.H >= 2 ? P.H - 2 : 0) || !row_owned(P, yrow)) return;   // block-uniform
     }
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tx = tid & 15, ty = tid >> 4;
     const int lox = slab_lo(bx), upx = slab_up(bx, P.W), loy = slab_lo(by), upy = slab_up(by, P.H);
     const bool degenerate = (upx - lox) <= 0 || (upy - loy) <= 0;
     int x = bx * kSlab + tx - 1, y = by * kSlab + ty - 1;
@@ -335,10 +345,10 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
     f3 front, back;
     ray_endpoints(P, x, y, front, back);
     float cl = vlen3(front.x - P.cam_pos[0], front.y - P.cam_pos[1], front.z - P.cam_pos[2]);
-    red[threadIdx.x] = cl;
+    red[tid] = cl;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + s]);
+        if (tid < s) red[tid] = fminf(red[tid], red[tid + s]);
         __syncthreads();
     }
     float rd = degenerate ? cl : red[0];
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
 
     // write ownership (pin 10) and one writer per pixel
     const int ox = owner_slab(x, P.W, P.nbx, P.conflict_x), oy = owner_slab(y, P.H, P.nby, P.conflict_y);
-    bool writer = !border && ox == bx && oy == by;
+    bool writer = !border && ox == bx && oy == by && !ghost;
     // among interior threads clamped onto the same pixel keep the one whose unclamped
     // coordinate equals the pixel, or (pin 10 case: none does) the first interior one
     {
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
     }
     // neighbour thread indices, clamped to the footprint
     int nl, nr, nt, nb;
-    if (degenerate) { nl = nr = nt = nb = threadIdx.x; }
+    if (degenerate) { nl = nr = nt = nb = tid; }
     else {
         int xl = max(lox, min(x - 1, upx - 1)), xr = max(lox, min(x + 1, upx - 1));
         int yt = max(loy, min(y + 1, upy - 1)), yb = max(loy, min(y - 1, upy - 1));
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
 #pragma unroll
                 for (int u = 0; u < PU; ++u) {
                     const int i = i0 + u;
-                    cache[i][threadIdx.x] = (uint8_t)classify_index<VOXEL>(C[u], tx_[u], ty_[u], tz_[u]);
+                    cache[i][tid] = (uint8_t)classify_index<VOXEL>(C[u], tx_[u], ty_[u], tz_[u]);
                     if (INSTR && bricks && mine && i >= 1 && i <= 30 && bounds_check(tx_[u], ty_[u], tz_[u])) mark_bricks(bricks, V, tx_[u], ty_[u], tz_[u]);
                 }
             }
@@ -429,11 +439,11 @@ __global__ __launch_bounds__(256) void march_phong_kernel(FrameParams P, VolumeV
                 float vd = (float)i * r.sstep + dist;                                 // :254
                 if (vd > r.upper) break;
                 if (INSTR) executed++;
-                uint32_t s = cache[i][threadIdx.x];
+                uint32_t s = cache[i][tid];
                 float4 e = lds_tf[s];
                 float cr = e.x, cg = e.y, cb = e.z, ca = e.w;
                 if (ca > kEps) {                                                      // :164 (phong is on)
-                    const uint32_t qf = cache[i - 1][threadIdx.x], qa = cache[i + 1][threadIdx.x];
+                    const uint32_t qf = cache[i - 1][tid], qa = cache[i + 1][tid];
                     const uint32_t ql = cache[i][nl], qr = cache[i][nr], qt = cache[i][nt], qb = cache[i][nb];
                     float direct = 0.f;
                     // all three central differences zero (inside a plateau): the gradient is (0,0,0),
@@ -502,13 +512,20 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
         hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 2>), grid, dim3(256), (size_t)a.lds_reserve, s,
                            a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
 }
+template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB>
+static void launch_phong_spb(const MarchArgs &a, hipStream_t s)
+{
+    const int rows = a.slabs.n_regular + 1;                   // grid rows, dealt to the 8 XCDs round-robin
+    dim3 grid((unsigned)(((rows + 7) / 8) * 8 * ((a.P.nbx + SPB - 1) / SPB)));
+    hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR, SPB>), grid, dim3(256 * SPB), (size_t)a.lds_reserve_phong, s,
+                       a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
+}
 template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 static void launch_phong(const MarchArgs &a, hipStream_t s)
 {
-    const int rows = a.slabs.n_regular + 1;                   // grid rows, dealt to the 8 XCDs round-robin
-    dim3 grid((unsigned)(((rows + 7) / 8) * 8 * a.P.nbx));
-    hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), (size_t)a.lds_reserve_phong, s,
-                       a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
+    if (a.phong_spb >= 4) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 4>(a, s);
+    else if (a.phong_spb == 2) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 2>(a, s);
+    else launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 1>(a, s);
 }
 
 template <int SLICE, int VOXEL, bool TEX8>
