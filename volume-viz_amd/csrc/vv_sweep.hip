@@ -475,6 +475,11 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
     int pw = 0;                               // published progress of this wave
     int kl = kmin;                            // slices k < kl have landed
     int stall_run = 0, n_iter = 0, n_stall = 0;
+    // the lane's candidate sample (valid while `cand`): position, texture coordinates, weights, voxel / slice indices
+    bool cand = false, inb = false;
+    float qx = 0.f, qy = 0.f, qz = 0.f, wx = 0.f, wy = 0.f, wz = 0.f, ctx_ = 0.f, cty_ = 0.f, ctz_ = 0.f;
+    uint32_t ix = 0;
+    int ir = 0, k0 = 0, need = 0;
     const int needoff = S.sgn > 0 ? 1 : 0;
     unsigned long long t_stall = 0, t_c0 = __builtin_readcyclecounter(), t_s = 0;
     const unsigned long long t_loop0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -502,35 +507,43 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             if (lane == 0) lds_store_i(&ctl->progress[wave], kInf);
         }
         tail = __builtin_amdgcn_readfirstlane(tail);
-        if (!tail) { const i4v l4 = lds_load_i4(ctl->landed); kl = min(min(l4.x, l4.y), min(l4.z, l4.w)); }
-        asm volatile("" ::: "memory");        // the flag is read before any slice data of this step
 
-        // ---- candidate: sample i of the open chunk (kernel.cu:136-141) ----
-        const float qx = px + r.sdir.x, qy = py + r.sdir.y, qz = pz + r.sdir.z;
-        const float tx = __builtin_fmaf(qx - 0.5f, P.inv_scale[0], 0.5f);
-        const float ty = __builtin_fmaf(qy - 0.5f, P.inv_scale[1], 0.5f);
-        const float tz = __builtin_fmaf(qz - 0.5f, P.inv_scale[2], 0.5f);
-        uint32_t ix, iy, iz;
-        const float wx = axis_coord<TEX8>(tx, (float)V.nx, (float)(V.nx - 1), ix);
-        const float wy = axis_coord<TEX8>(ty, (float)V.ny, (float)(V.ny - 1), iy);
-        const float wz = axis_coord<TEX8>(tz, (float)V.nz, (float)(V.nz - 1), iz);
-        const int is = (int)(MAJOR == 2 ? iz : iy), ir = (int)(MAJOR == 2 ? iy : iz);
-        const int k0 = (is ^ kxor) + kxadd;              // position of slice `is`; slice is + 1 sits at k0 + kmul
-        const int need = k0 + needoff;                   // the later of the two
-        // ---- release slices no lane of this wave will read again: a ray's positions only grow, so the earlier slice of
-        //      its candidate bounds everything it will still read.  Done before the wave may stall: a wave that waits
-        //      for slices far ahead must not hold the ring back (its published progress gates the loaders) ----
-        if (!tail) {
-            const int fr = need - 1;
-            if (!any_(alive && fr <= pw)) {
-                const int m = wave_min_fast(alive ? fr : kInf);
-                if (m < kInf && m > pw) {
-                    pw = m;
-                    if (lane == 0) lds_store_i(&ctl->progress[wave], pw);
+        // ---- candidate: sample i of the open chunk (kernel.cu:136-141).  Computed once per sample: while a lane waits for
+        //      its slices its candidate stays valid, so an iteration in which nothing changed costs a dozen instructions.
+        //      (Recomputing for lanes whose candidate is still valid gives the same values: no selects.) ----
+        const bool open = alive && i != 0;
+        if (any_(open && !cand)) {
+            qx = px + r.sdir.x; qy = py + r.sdir.y; qz = pz + r.sdir.z;
+            const float tx = __builtin_fmaf(qx - 0.5f, P.inv_scale[0], 0.5f);
+            const float ty = __builtin_fmaf(qy - 0.5f, P.inv_scale[1], 0.5f);
+            const float tz = __builtin_fmaf(qz - 0.5f, P.inv_scale[2], 0.5f);
+            uint32_t iy, iz;
+            wx = axis_coord<TEX8>(tx, (float)V.nx, (float)(V.nx - 1), ix);
+            wy = axis_coord<TEX8>(ty, (float)V.ny, (float)(V.ny - 1), iy);
+            wz = axis_coord<TEX8>(tz, (float)V.nz, (float)(V.nz - 1), iz);
+            inb = bounds_check(tx, ty, tz);
+            ctx_ = tx; cty_ = ty; ctz_ = tz;
+            const int is = (int)(MAJOR == 2 ? iz : iy);
+            ir = (int)(MAJOR == 2 ? iy : iz);
+            k0 = (is ^ kxor) + kxadd;                    // position of slice `is`; slice is + 1 sits at k0 + kmul
+            need = k0 + needoff;                         // the later of the two
+            cand = open;
+            // ---- release slices no lane of this wave will read again: a ray's positions only grow, so the earlier slice of
+            //      its candidate bounds everything it will still read.  Done before the wave may stall: a wave that waits
+            //      for slices far ahead must not hold the ring back (its published progress gates the loaders) ----
+            if (!tail) {
+                const int fr = need - 1;
+                if (!any_(alive && fr <= pw)) {
+                    const int m = wave_min_fast(alive ? fr : kInf);
+                    if (m < kInf && m > pw) {
+                        pw = m;
+                        if (lane == 0) lds_store_i(&ctl->progress[wave], pw);
+                    }
                 }
             }
         }
-        const bool open = alive && i != 0;
+        if (!tail) { const i4v l4 = lds_load_i4(ctl->landed); kl = min(min(l4.x, l4.y), min(l4.z, l4.w)); }
+        asm volatile("" ::: "memory");        // the flag is read before any slice data of this step
         const bool take = open && (tail != 0 || need < kl);
         if (!any_(take)) {
             if (any_(alive && i == 0)) continue;         // an empty chunk: open the next one
@@ -543,13 +556,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
 #ifdef VV_SWEEP_DEBUG
                 {
                     const int mn = wave_min_fast(open ? need : kInf);
-                    if (lane == 0) {
-                        for (int w = 0; w < S.nl; ++w) printf("  loader %d: landed %d | waiting: kn %d ke %d pr %d pos %d np %d head %d gi %d idle %d | owners %d %d %d\n", w, ctl->landed[w], ctl->dbg[w][0], ctl->dbg[w][1], ctl->dbg[w][2], ctl->dbg[w][3], ctl->dbg[w][4], ctl->dbg[w][5], ctl->dbg[w][6], ctl->dbg[w][7],
-                            ctl->owner[ctl->dbg[w][3]], ctl->owner[ctl->dbg[w][3] + 1], ctl->owner[ctl->dbg[w][3] + ctl->dbg[w][4] - 1]);
-                    }
-                    if (lane == 0) printf("watchdog tile (%d,%d) wave %d: kl %d loaded %d min need %d pw %d kmin %d kmax %d progress %d %d %d %d %d %d %d %d %d %d %d %d\n", tcol, trow, wave, kl,
-                        lds_load_i(&ctl->landed[0]), mn, pw, kmin, lds_load_i(&ctl->kmax), ctl->progress[0], ctl->progress[1], ctl->progress[2], ctl->progress[3], ctl->progress[4], ctl->progress[5],
-                        ctl->progress[6], ctl->progress[7], ctl->progress[8], ctl->progress[9], ctl->progress[10], ctl->progress[11]);
+                    if (lane == 0) printf("watchdog tile (%d,%d) wave %d: kl %d min need %d pw %d kmin %d kmax %d\n", tcol, trow, wave, kl, mn, pw, kmin, lds_load_i(&ctl->kmax));
                 }
 #endif
                 if (lane == 0) { lds_store_i(&ctl->err, 3); lds_store_i(&ctl->progress[wave], kInf); }
@@ -579,15 +586,15 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             const float f1 = __builtin_fmaf(wy, e11 - e01, e01);
             const float L = __builtin_fmaf(wz, f1 - f0, f0);
             idx = min((uint32_t)(L * 255.0f), 255u);
-            idx = bounds_check(tx, ty, tz) ? idx : 0u;
-            if (INSTR && take && bounds_check(tx, ty, tz)) {
+            idx = inb ? idx : 0u;
+            if (INSTR && take && inb) {
                 const int *bx0 = ctl->box[k0 & (kTab - 1)], *bx1 = ctl->box[(k0 + kmul) & (kTab - 1)];
                 const bool ok = (int)ix >= bx0[0] && (int)ix + 1 <= bx0[1] && ir >= bx0[2] && ir + 1 <= bx0[3] &&
                                 (int)ix >= bx1[0] && (int)ix + 1 <= bx1[1] && ir >= bx1[2] && ir + 1 <= bx1[3];
                 if (!ok) ++misses;
             }
         } else {
-            idx = V.big ? sample_index<VV_VOXEL_F32, TEX8, true>(V, tx, ty, tz) : sample_index<VV_VOXEL_F32, TEX8, false>(V, tx, ty, tz);
+            idx = V.big ? sample_index<VV_VOXEL_F32, TEX8, true>(V, ctx_, cty_, ctz_) : sample_index<VV_VOXEL_F32, TEX8, false>(V, ctx_, cty_, ctz_);
         }
         float cr, cg, cb, ca;
         ca = lds_tf[768 + idx];
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         else { cg = lds_tf[256 + idx]; cb = lds_tf[512 + idx]; }
         if (INSTR && take) {
             executed++;
-            if (bricks && bounds_check(tx, ty, tz)) mark_bricks(bricks, V, tx, ty, tz);
+            if (bricks && inb) mark_bricks(bricks, V, ctx_, cty_, ctz_);
         }
         {
             // :268-270 + blend :107-118, predicated (the table is finite)
@@ -608,7 +615,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         }
         const bool hit = take && res_a > P.ert_thr;                      // :272-274
         ert = ert || hit;
-        if (take) { px = qx; py = qy; pz = qz; ++i; }
+        if (take) { px = qx; py = qy; pz = qz; ++i; cand = false; }
         // the chunk ends after its last sample, or -- the ray terminating early -- after this one
         if (take && (i > n || hit)) {
 #pragma clang fp contract(off)
