@@ -4,6 +4,14 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm bundles its own HIP / HSA runtime.  Whichever runtime opens the GPU first in a process wins and the other
+# then finds no device, so torch (used by a few GPU tests and by bench.py) is imported before libvolviz_hip.so is loaded:
+# the library then binds to the runtime torch has already mapped (same SONAME) whichever test files are selected.
+try:
+    import torch  # noqa: F401
+except Exception:                                                   # the CPU-only checks do not need it
+    torch = None
+
 REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "volume-viz_amd", "python"))

@@ -66,6 +66,8 @@ void launch_raymarch_wstaged(const MarchArgs &a, hipStream_t s);  // wave-privat
 void launch_raymarch_sweep(const MarchArgs &a, hipStream_t s);    // block-wide slab sweep, LDS slice ring filled by LDS-DMA (f32, no Phong)
 // host-side sizing of the sweep for a frame (fills a.sweep; enabled = 0 if the frame does not qualify)
 void plan_sweep(MarchArgs &a, int first_tile_row_px, int n_pixel_rows, int own_bands);
+// the axis (1 = y, 2 = z) and direction along which every ray of the frame crosses the volume's slices, or false
+bool sweep_axis(const FrameParams &P, const VolumeView &V, int &major, int &sgn, const char **why);
 
 struct SliceArgs {
     VolumeView V; int V_type; bool tex8;

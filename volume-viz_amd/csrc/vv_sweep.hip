@@ -26,6 +26,7 @@
 // ring and takes those sparse samples by direct gathers like march_kernel.
 #include "vv_device.h"
 #include "vv_kernels.h"
+#include "vv_frustum.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -43,7 +44,6 @@ constexpr int kMaxChunks = 60;                 // rows (= LDS-DMA instructions) 
 constexpr int kPage = 1024;                    // the ring is handed out in pages
 constexpr int kPages = (kLdsMax - kRingOff) / kPage;
 constexpr int kTab = 32;                       // slices the ring can hold at once (table entries)
-constexpr float kMargin = 0.0625f;             // voxels added around the analytic footprint (float rounding is < 0.01)
 
 typedef int __attribute__((ext_vector_type(4))) i4v;
 typedef int __attribute__((ext_vector_type(2))) i2v;
@@ -60,52 +60,6 @@ struct Ctl {                                   // control block in LDS
     int dbg[4][8];                             // debug builds: what each loader wave is doing
 };
 static_assert(sizeof(Ctl) <= kCtlBytes, "control block");
-
-// Tile frustum in voxel-float coordinates (vb = tex * n - 0.5): eye E and the extreme slopes of the
-// four corner rays against the sweep coordinate.  Every ray of the tile runs inside the hull of the
-// corner rays (directions are affine in the pixel coordinates, ray_endpoints()).
-struct Frustum { float Ex, Er, Es, mx_lo, mx_hi, mr_lo, mr_hi; };
-
-template <int MAJOR>
-__device__ __host__ inline void axis_pick(const float v[3], float &x, float &r, float &s)
-{
-    x = v[0]; r = MAJOR == 2 ? v[1] : v[2]; s = MAJOR == 2 ? v[2] : v[1];
-}
-
-// Footprint of the frustum in slice s: voxel columns x0..x1 and rows r0..r1 (inclusive) that any in-volume
-// sample interpolating with slice s can touch.  Those are the samples whose sweep coordinate zeta lies in
-// [s - 1, s + 1), plus -- slice 1 only, kept for all -- the in-volume samples with zeta in [-0.5, 0), which clamp
-// to slice 0 and read slice 1 with weight 0 (the value must still be finite).  The eye lies outside the slab
-// range (plan_sweep), so (zeta - Es) keeps one sign and each bound is ONE corner slope times a linear function of
-// s: bound(s) = a + m * s, four fused multiply-adds per slice.
-struct Foot { int x0, x1, r0, r1; };
-struct FootLin { float ax_lo, mx_lo, ax_hi, mx_hi, ar_lo, mr_lo, ar_hi, mr_hi; };
-__device__ __host__ inline void foot_linear(const Frustum &F, bool ahead /* zeta - Es > 0 */, FootLin &L)
-{
-    const float c0 = -1.5f, c1 = 1.0f;                 // the slab is [s + c0, s + c1)
-    auto pick = [&](float mlo, float mhi, float E, float &a_lo, float &m_lo, float &a_hi, float &m_hi) {
-        // ahead: min over {mlo, mhi} x {z0, z1} is mlo * (mlo >= 0 ? z0 : z1), max is mhi * (mhi >= 0 ? z1 : z0);
-        // behind (z < 0): min is mhi * (mhi >= 0 ? z0 : z1), max is mlo * (mlo >= 0 ? z1 : z0)
-        m_lo = ahead ? mlo : mhi; m_hi = ahead ? mhi : mlo;
-        const float cl = m_lo >= 0.f ? c0 : c1, ch = m_hi >= 0.f ? c1 : c0;
-        a_lo = E - kMargin + m_lo * (cl - F.Es);
-        a_hi = E + kMargin + m_hi * (ch - F.Es);
-    };
-    pick(F.mx_lo, F.mx_hi, F.Ex, L.ax_lo, L.mx_lo, L.ax_hi, L.mx_hi);
-    pick(F.mr_lo, F.mr_hi, F.Er, L.ar_lo, L.mr_lo, L.ar_hi, L.mr_hi);
-}
-__device__ __forceinline__ Foot footprint(const FootLin &L, int s, int nx, int nr)
-{
-    const float fs = (float)s;
-    const float xlo = __builtin_fmaf(L.mx_lo, fs, L.ax_lo), xhi = __builtin_fmaf(L.mx_hi, fs, L.ax_hi);
-    const float rlo = __builtin_fmaf(L.mr_lo, fs, L.ar_lo), rhi = __builtin_fmaf(L.mr_hi, fs, L.ar_hi);
-    Foot f;
-    f.x0 = (int)fminf(fmaxf(floorf(xlo), 0.f), (float)(nx - 1));
-    f.x1 = (int)fminf(fmaxf(floorf(xhi), 0.f), (float)(nx - 1)) + 1;
-    f.r0 = (int)fminf(fmaxf(floorf(rlo), 0.f), (float)(nr - 1));
-    f.r1 = (int)fminf(fmaxf(floorf(rhi), 0.f), (float)(nr - 1)) + 1;
-    return f;
-}
 
 // minimum over the wave / over each row of 16 lanes by DPP (no LDS traffic)
 template <int CTRL, int ROWMASK> __device__ __forceinline__ int dpp_min(int v)
@@ -232,24 +186,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         const int lw = wave - S.nc;
         // frustum of the tile from its four corner pixels (pixel centres, ray_endpoints())
         Frustum F;
-        {
-            float h[3], nn[3] = {(float)V.nx, (float)V.ny, (float)V.nz}, E[3];
-            for (int a = 0; a < 3; ++a) { h[a] = 0.5f * P.inv_scale[a]; E[a] = (P.cam_pos[a] * h[a] + 0.5f) * nn[a] - 0.5f; }
-            axis_pick<MAJOR>(E, F.Ex, F.Er, F.Es);
-            F.mx_lo = F.mr_lo = INFINITY; F.mx_hi = F.mr_hi = -INFINITY;
-            for (int c = 0; c < 4; ++c) {
-                const int px = x0 + ((c & 1) ? tile_w - 1 : 0), py = y0 + ((c & 2) ? tile_h - 1 : 0);
-                const float ndx = (2.0f * ((float)px + 0.5f)) / (float)P.W - 1.0f, ndy = (2.0f * ((float)py + 0.5f)) / (float)P.H - 1.0f;
-                const float sx = ndx * P.tan_half_x, sy = ndy * P.tan_half_y;
-                float D[3];
-                for (int a = 0; a < 3; ++a) D[a] = ((P.side[a] * sx + P.up[a] * sy) + P.look[a]) * h[a] * nn[a];
-                float dx, dr, ds;
-                axis_pick<MAJOR>(D, dx, dr, ds);
-                const float mx = dx / ds, mr = dr / ds;
-                F.mx_lo = fminf(F.mx_lo, mx); F.mx_hi = fmaxf(F.mx_hi, mx);
-                F.mr_lo = fminf(F.mr_lo, mr); F.mr_hi = fmaxf(F.mr_hi, mr);
-            }
-        }
+        tile_frustum<MAJOR>(P, V, x0, y0, x0 + tile_w - 1, y0 + tile_h - 1, F);
         FootLin FL;
         foot_linear(F, S.sgn > 0, FL);
         // one LDS-DMA piece = one row of the slice's image: lane l copies bytes [16 l, 16 l + 16) of the row
@@ -678,6 +615,43 @@ void launch_raymarch_sweep(const MarchArgs &a, hipStream_t s)
     if (a.sweep.major == 2) sweepk::launch_major<2>(a, s); else sweepk::launch_major<1>(a, s);
 }
 
+bool sweep_axis(const FrameParams &P, const VolumeView &V, int &major, int &sgn, const char **why)
+{
+    const char *dummy; if (!why) why = &dummy;
+    major = 0; sgn = 0;
+    if (P.ray_mode != VV_RAYS_ANALYTIC || P.quantize8) { *why = "rays from images / quantised"; return false; }
+    if (P.W < 2 || P.H < 2) { *why = "degenerate frame"; return false; }
+    const double n[3] = {(double)V.nx, (double)V.ny, (double)V.nz};
+    double h[3], E[3];
+    bool outside = false;
+    for (int a = 0; a < 3; ++a) {
+        h[a] = 0.5 * (double)P.inv_scale[a];
+        E[a] = ((double)P.cam_pos[a] * h[a] + 0.5) * n[a] - 0.5;
+        if (fabs((double)P.cam_pos[a]) > (double)P.scale[a] * 1.0001) outside = true;
+    }
+    if (!outside) { *why = "eye inside the cube"; return false; }         // front = (0,0,0) rays (kernel.cu:317-321 quirk)
+    auto dirD = [&](double px, double py, double D[3]) {
+        const double sx = ((2.0 * (px + 0.5)) / P.W - 1.0) * P.tan_half_x, sy = ((2.0 * (py + 0.5)) / P.H - 1.0) * P.tan_half_y;
+        for (int a = 0; a < 3; ++a) D[a] = (P.side[a] * sx + P.up[a] * sy + P.look[a]) * h[a] * n[a];
+    };
+    // y or z, the one every ray of the frame crosses most steeply, all in the same direction
+    double best_q = 0.0;
+    for (int ax = 1; ax <= 2; ++ax) {
+        double lo = INFINITY, hi = -INFINITY, q = INFINITY;
+        for (int c = 0; c < 4; ++c) {
+            double D[3]; dirD((c & 1) ? P.W - 1 : 0, (c & 2) ? P.H - 1 : 0, D);
+            const double len = sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
+            lo = std::min(lo, D[ax]); hi = std::max(hi, D[ax]); q = std::min(q, fabs(D[ax]) / len);
+        }
+        if (lo * hi <= 0.0) continue;                                     // rays cross these planes both ways
+        // the eye must sit before the first slice (every in-volume point has (zeta - Es) of one sign)
+        if (lo > 0.0 ? !(E[ax] < -1.5) : !(E[ax] > n[ax] + 1.5)) continue;
+        if (q > best_q) { best_q = q; major = ax; sgn = lo > 0.0 ? 1 : -1; }
+    }
+    if (!major || best_q < 0.35) { major = 0; *why = "no sweep axis: rays cross the x-y and x-z planes both ways or too flatly, or the eye is beside the slices"; return false; }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host-side plan: does the frame qualify, along which axis, and how large must the LDS image of a
 // slice be.  Mirrors the device's footprint() in double precision with slack, so the device never
@@ -700,32 +674,13 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     if (P.W < 2 || P.H < 2 || n_rows_px < 1) VV_NO("degenerate frame");
     const double n[3] = {(double)V.nx, (double)V.ny, (double)V.nz};
     double h[3], E[3];
-    bool outside = false;
-    for (int a = 0; a < 3; ++a) {
-        h[a] = 0.5 * (double)P.inv_scale[a];
-        E[a] = ((double)P.cam_pos[a] * h[a] + 0.5) * n[a] - 0.5;
-        if (fabs((double)P.cam_pos[a]) > (double)P.scale[a] * 1.0001) outside = true;
-    }
-    if (!outside) VV_NO("eye inside the cube");                                                 // eye inside the cube: front = (0,0,0) rays (kernel.cu:317-321 quirk)
+    for (int a = 0; a < 3; ++a) { h[a] = 0.5 * (double)P.inv_scale[a]; E[a] = ((double)P.cam_pos[a] * h[a] + 0.5) * n[a] - 0.5; }
     auto dirD = [&](double px, double py, double D[3]) {
         const double sx = ((2.0 * (px + 0.5)) / P.W - 1.0) * P.tan_half_x, sy = ((2.0 * (py + 0.5)) / P.H - 1.0) * P.tan_half_y;
         for (int a = 0; a < 3; ++a) D[a] = (P.side[a] * sx + P.up[a] * sy + P.look[a]) * h[a] * n[a];
     };
-    // sweep axis: y or z, the one every ray of the frame crosses most steeply, all in the same direction
-    int best = 0, best_sgn = 0; double best_q = 0.0;
-    for (int ax = 1; ax <= 2; ++ax) {
-        double lo = INFINITY, hi = -INFINITY, q = INFINITY;
-        for (int c = 0; c < 4; ++c) {
-            double D[3]; dirD((c & 1) ? P.W - 1 : 0, (c & 2) ? P.H - 1 : 0, D);
-            const double len = sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
-            lo = std::min(lo, D[ax]); hi = std::max(hi, D[ax]); q = std::min(q, fabs(D[ax]) / len);
-        }
-        if (lo * hi <= 0.0) continue;                                     // rays cross these planes both ways
-        // the eye must sit before the first slice (every in-volume point has (zeta - Es) of one sign)
-        if (lo > 0.0 ? !(E[ax] < -1.5) : !(E[ax] > n[ax] + 1.5)) continue;
-        if (q > best_q) { best_q = q; best = ax; best_sgn = lo > 0.0 ? 1 : -1; }
-    }
-    if (!best || best_q < 0.35) VV_NO("no sweep axis: rays cross the x-y and x-z planes both ways or too flatly, or the eye is beside the slices");
+    int best = 0, best_sgn = 0;
+    { const char *why = nullptr; if (!sweep_axis(P, V, best, best_sgn, &why)) VV_NO(why); }
     // sample spacing along the sweep axis, in slices: beyond ~3 whole slices would be streamed for nothing
     {
         const double dz = (double)P.step[best] * (double)P.inv_scale[best] * n[best];
