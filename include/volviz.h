@@ -306,6 +306,11 @@ int                vv_debug_counters(vv_context *ctx, unsigned long long out[16]
  * 8 words per block (start, march start, end in 10 ns ticks; hardware ids; tile; slice range; chunks; valid).
  * Returns the number of blocks copied. */
 int                vv_debug_sweep_trace(vv_context *ctx, unsigned long long *out, int max_blocks);
+/* The slab-sweep planner on its own (host arithmetic, no device): would this frame qualify for vv_sweep.hip's kernel and
+ * with which tile / LDS image sizes?  out = {enabled, major (1 = y, 2 = z), sgn, wx, wy, pxc, ry, group, ring, ntx, nty, nl}. */
+int                vv_debug_plan_sweep(int width, int height, const struct camera_params *camera, const vv_ray_source *rays,
+                                       const float step[3], int voxel_type, int nx, int ny, int nz, int phong, int slice_type,
+                                       int out[12]);
 /* The VV_* developer knobs of the environment are read when a context is created and at every volume load, never
  * per frame; this reads them again (tests that flip a knob between two frames of one volume). */
 int                vv_reread_env(vv_context *ctx);

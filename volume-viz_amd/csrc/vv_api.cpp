@@ -106,6 +106,7 @@ static int ensure(vv_context *c, void **p, size_t *cap, size_t need)
 }
 
 static int finalize_layout(vv_context *c, hipStream_t st);
+static int camera_basis(vv_context *c, FrameParams &P, const camera_params *cam, const vv_ray_source *rays, int W, int H);
 static bool ensure_bricks(vv_context *c, hipStream_t st);
 static bool ensure_zpair(vv_context *c, hipStream_t st);
 
@@ -242,6 +243,38 @@ int vv_prepare_layouts(vv_context *c, int which, void *stream)
     if ((which & VV_LAYOUT_BRICKED) && ensure_bricks(c, st)) built |= VV_LAYOUT_BRICKED;
     if ((which & VV_LAYOUT_ZPAIR) && ensure_zpair(c, st)) built |= VV_LAYOUT_ZPAIR;
     return built;
+}
+
+// The sweep planner on its own (host arithmetic only: no device is touched), for tests and for callers that want to know
+// whether a frame would qualify: out = {enabled, major, sgn, wx, wy, pxc, ry, group, ring, ntx, nty, nl}.
+int vv_debug_plan_sweep(int W, int H, const camera_params *cam, const vv_ray_source *rays, const float step[3],
+                        int voxel_type, int nx, int ny, int nz, int phong, int slice_type, int out[12])
+{
+    if (!cam || !rays || !step || !out || W < 1 || H < 1 || nx < 1 || ny < 1 || nz < 1) return VV_ERR_INVALID;
+    MarchArgs A;
+    memset(&A, 0, sizeof A);
+    FrameParams &P = A.P;
+    P.W = W; P.H = H;
+    P.nbx = W / kSlab + ((W % kSlab) ? 1 : 0); P.nby = H / kSlab + ((H % kSlab) ? 1 : 0);
+    P.rb = 0; P.re = P.nby; P.band = 4; P.count = 1; P.index = 0;
+    P.slice_type = slice_type;
+    for (int a = 0; a < 3; ++a) {
+        if (!(cam->scale[a] > 0.f)) return VV_ERR_INVALID;
+        P.cam_pos[a] = cam->origin[a]; P.scale[a] = cam->scale[a]; P.inv_scale[a] = 1.0f / cam->scale[a]; P.step[a] = step[a];
+    }
+    P.ray_mode = rays->mode; P.quantize8 = rays->quantize8;
+    if (rays->mode == VV_RAYS_ANALYTIC) { int rc = camera_basis(nullptr, P, cam, rays, W, H); if (rc) return rc; }
+    const uint32_t vsz = voxel_type == VV_VOXEL_F32 ? 4u : 1u;
+    A.V.data = (const void *)(uintptr_t)256; A.V.nx = nx; A.V.ny = ny; A.V.nz = nz;
+    A.V.row_bytes = (uint32_t)nx * vsz; A.V.slice_bytes = A.V.row_bytes * (uint32_t)ny;
+    A.V_type = voxel_type; A.phong = phong != 0;
+    A.sweep.nl = A.sweep.wx = A.sweep.wy = A.sweep.group = A.sweep.depth = A.sweep.lead = -1;
+    const int last_written = H >= 2 ? H - 2 : 0;
+    plan_sweep(A, 0, ((last_written + 1 + 7) / 8) * 8, 0);
+    const SweepArgs &S = A.sweep;
+    const int v[12] = {S.enabled, S.major, S.sgn, S.wx, S.wy, S.pxc, S.ry, S.group, S.ring, S.ntx, S.nty, S.nl};
+    memcpy(out, v, sizeof v);
+    return VV_OK;
 }
 
 int vv_reread_env(vv_context *c)

@@ -78,7 +78,7 @@ EXPORTS = [
     "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid", "vv_debug_counters",
     "vv_first_pass", "vv_cut_plane_canonical", "vv_cut_plane_to_slice_params", "vv_slice_to_bgra",
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
-    "vv_prepare_layouts", "vv_device_bytes", "vv_debug_sweep_trace", "vv_reread_env",
+    "vv_prepare_layouts", "vv_device_bytes", "vv_debug_sweep_trace", "vv_reread_env", "vv_debug_plan_sweep",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
 ]
 
@@ -135,6 +135,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_debug_counters.argtypes = [vp, vp]
     lib.vv_debug_sweep_trace.argtypes = [vp, vp, i]
     lib.vv_reread_env.argtypes = [vp]
+    lib.vv_debug_plan_sweep.argtypes = [i, i, C.POINTER(camera_params), C.POINTER(vv_ray_source), C.POINTER(f * 3), i, i, i, i, i, i, vp]
     lib.vv_prepare_layouts.argtypes = [vp, i, vp]
     lib.vv_device_bytes.argtypes = [vp, vp]
     lib.vv_volume_dims.argtypes = [vp, C.POINTER(i * 3), C.POINTER(i)]
@@ -188,6 +189,22 @@ class Camera:
         """glwidget.cpp:435-445 orbit position."""
         return Camera(origin=(r * np.sin(theta) * np.cos(phi), r * np.cos(theta),
                               r * np.sin(theta) * np.sin(phi)), **kw)
+
+
+def plan_sweep(width: int, height: int, cam: "Camera", step: float, voxel_type: int, dims, phong: bool = False,
+               slice_type: int = SLICE_NONE, rays=None) -> dict:
+    """vv_debug_plan_sweep: the slab-sweep planner's decision for a frame (host arithmetic only, needs no GPU)."""
+    lib = load_library()
+    cp = cam.params(width, height)
+    rs = rays if rays is not None else analytic_rays(cam)
+    st = (C.c_float * 3)(step, step, step) if np.isscalar(step) else (C.c_float * 3)(*step)
+    out = np.zeros(12, np.int32)
+    rc = lib.vv_debug_plan_sweep(width, height, C.byref(cp), C.byref(rs), C.byref(st), voxel_type, dims[0], dims[1], dims[2],
+                                 int(phong), slice_type, out.ctypes.data)
+    if rc:
+        raise VolvizError(rc, "vv_debug_plan_sweep")
+    keys = ("enabled", "major", "sgn", "wx", "wy", "pxc", "ry", "group", "ring", "ntx", "nty", "nl")
+    return dict(zip(keys, (int(v) for v in out)))
 
 
 def analytic_rays(cam: Camera, quantize8: bool = False, aspect: float = 0.0) -> vv_ray_source:
