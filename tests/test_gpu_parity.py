@@ -485,12 +485,14 @@ def test_sweep_kernel_is_bit_identical(ctx, view, monkeypatch):
         assert n_got == n
 
 
-@pytest.mark.parametrize("spb", [2, 4])
-def test_phong_blocks_of_several_slabs_are_bit_identical(ctx, spb, monkeypatch):
-    """march_phong_kernel with 2 or 4 x-adjacent slabs per block (each slab keeps its own apron, radius and sample
-    cache; speed only): the sweep's cases with Phong forced on, frame widths that leave ghost slabs at the row's end,
-    W == 1 (mod 14), shards, every layout -- same frames, same sample counts."""
+@pytest.mark.parametrize("spb,compact", [(1, 0), (2, 0), (1, 1), (2, 1)])
+def test_phong_blocks_of_several_slabs_are_bit_identical(ctx, spb, compact, monkeypatch):
+    """march_phong_kernel's launch forms (speed only): one or two x-adjacent slabs per block (each slab keeps its own
+    apron, radius and sample cache), and the cache refresh either by every thread for its own ray or dealt out as
+    (needed ray, quarter) work items.  The sweep's cases with Phong forced on, frame widths that leave ghost slabs at
+    the row's end, W == 1 (mod 14), shards, every layout, instrumented and not -- same frames, same sample counts."""
     monkeypatch.setenv("VV_PHONG_SPB", str(spb))
+    monkeypatch.setenv("VV_PHONG_COMPACT", str(compact))
     for seed in range(0, 48, 5):
         vol, tf, W, H, cam, sp, _, o = _random_case(seed)
         ctx.load_volume(vol, tf)
@@ -500,6 +502,9 @@ def test_phong_blocks_of_several_slabs_are_bit_identical(ctx, spb, monkeypatch):
         want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=True, options=opts, fill=0x3C)
         assert_frames_close(got, want, f"phong spb={spb} seed {seed}: {vol.shape} {vol.dtype} {W}x{H}")
         assert n_got == n
+        o2 = dict(o); o2["count_samples"] = False
+        got2 = ctx.render(W, H, cam, slice=sp, phong=True, options=vv.make_options(**o2), fill=0x3C)      # the uninstrumented build
+        assert np.array_equal(got2, got), f"phong spb={spb} compact={compact} seed {seed} (uninstrumented)"
     vol = O.draw_default_brain(64, 64, 64)
     tf = vv.transfer_preset(vv.TF_ENGINE)
     ctx.load_volume(vol, tf)

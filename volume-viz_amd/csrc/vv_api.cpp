@@ -22,7 +22,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, wstaged = 0, sweep = -1, sweep_trace = 0, force_big = 0;
-    int phong_spb = -1;
+    int phong_spb = -1, phong_compact = -1;
     int sw_nl = -1, sw_wx = -1, sw_wy = -1, sw_group = -1, sw_depth = -1, sw_lead = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
@@ -31,6 +31,7 @@ struct vv_knobs {
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1); wstaged = geti("VV_WSTAGED", 0);
         phong_spb = geti("VV_PHONG_SPB", -1);
+        phong_compact = geti("VV_PHONG_COMPACT", -1);
         sw_nl = geti("VV_SWEEP_NL", -1); sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_group = geti("VV_SWEEP_GROUP", -1);
         sw_depth = geti("VV_SWEEP_DEPTH", -1); sw_lead = geti("VV_SWEEP_LEAD", -1); sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
@@ -746,8 +747,14 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)
     A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f) ? 30000 : 13000);
     if (K.lds_reserve_phong >= 0 && K.lds_reserve_phong <= 146 * 1024) A.lds_reserve_phong = K.lds_reserve_phong;
-    A.phong_spb = 1;
-    if (K.phong_spb == 1 || K.phong_spb == 2 || K.phong_spb == 4) A.phong_spb = K.phong_spb;
+    // Two x-adjacent slabs per block (waves of 32 x 2 threads across both): measured with tools/ab_phong_cases.sh it
+    // wins only where the linear f32 volume is far beyond the caches and sparsely sampled (C3 + Phong 2.28 -> 2.16 ms,
+    // brain + engine table 2.21 -> 2.00) and loses 5-25 % everywhere else (cache-resident volumes, u8, bricks, the
+    // dense frames of the multi-GPU configurations, the 32 GiB volume), so that is the only case that uses it.
+    A.phong_spb = (!use_bricks && c->vtype == VV_VOXEL_F32 && beyond_caches && c->vol_bytes <= (8ull << 30) && density > 3.5f) ? 2 : 1;
+    if (K.phong_spb == 1 || K.phong_spb == 2) A.phong_spb = K.phong_spb;
+    // Cache refresh dealt out as (needed ray, quarter) items: 19 % fewer gathers on C3 + Phong, 4-6 % slower (opt-in)
+    A.phong_compact = K.phong_compact == 1;
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
     int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));

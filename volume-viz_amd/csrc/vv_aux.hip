@@ -332,7 +332,8 @@ size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_
 {
     const size_t brick = vtype == VV_VOXEL_F32 ? BrickGeom<VV_VOXEL_F32>::brick : BrickGeom<VV_VOXEL_U8>::brick;
     const size_t bxv = vtype == VV_VOXEL_F32 ? BrickGeom<VV_VOXEL_F32>::bx : BrickGeom<VV_VOXEL_U8>::bx;
-    const size_t nbx = ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
+    const bool xcol = vtype == VV_VOXEL_F32 && BrickGeom<VV_VOXEL_F32>::halo == 0;      // no halo voxel: one more (clamped) brick column instead
+    const size_t nbx = xcol ? (size_t)nx / bxv + 1 : ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
     size_t row = nbx * brick;                                     // brick sizes are multiples of 64
     // a row of bricks that is a multiple of 4 KiB gets 64 bytes more (same cache-channel effect as the
     // linear pitch, smaller: rotated C3 -1...-4 %, + Phong -4 %); VV_BRICK_PAD=<bytes, multiple of 64> / 0 overrides
@@ -365,8 +366,10 @@ void launch_build_bricks(int vtype, const void *linear, size_t row_pitch, size_t
 {
     constexpr int FBX = BrickGeom<VV_VOXEL_F32>::bx;
     const size_t bxv = vtype == VV_VOXEL_F32 ? FBX : 4;
-    const size_t nbx = ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
-    const size_t per_brick = vtype == VV_VOXEL_F32 ? 16 * (FBX + 1) : 128;
+    constexpr int FH = BrickGeom<VV_VOXEL_F32>::halo;
+    const bool xcol = vtype == VV_VOXEL_F32 && FH == 0;
+    const size_t nbx = xcol ? (size_t)nx / bxv + 1 : ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
+    const size_t per_brick = vtype == VV_VOXEL_F32 ? 16 * (FBX + FH) : 128;
     const size_t total = nbx * nby * nbz * per_brick;
     uint32_t sy = 0, sz64 = 0;
     brick_copy_bytes(vtype, nx, ny, nz, &sy, &sz64);
@@ -374,7 +377,7 @@ void launch_build_bricks(int vtype, const void *linear, size_t row_pitch, size_t
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (vtype == VV_VOXEL_F32)
-        hipLaunchKernelGGL((brick_kernel<float, FBX + 1, FBX>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, row_pitch, slice_pitch, (float *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
+        hipLaunchKernelGGL((brick_kernel<float, FBX + FH, FBX>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, row_pitch, slice_pitch, (float *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
     else
         hipLaunchKernelGGL((brick_kernel<uint8_t, 8, 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, row_pitch, slice_pitch, (uint8_t *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
 }

@@ -61,7 +61,10 @@ template <int VOXEL> struct BrickGeom;
 #ifndef VV_BRICK_XLOG2
 #define VV_BRICK_XLOG2 2          // f32 bricks are (1 << VV_BRICK_XLOG2) voxels long in x (experiment knob)
 #endif
-template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t xlog2 = VV_BRICK_XLOG2, bx = 1u << xlog2, row = (bx + 1) * 4, brick = 16 * row; };
+#ifndef VV_BRICK_HALO
+#define VV_BRICK_HALO 1           // f32 rows end in a copy of the next voxel in x (0: whole-line bricks, the x pair is two gathers)
+#endif
+template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t xlog2 = VV_BRICK_XLOG2, bx = 1u << xlog2, halo = VV_BRICK_HALO, row = (bx + halo) * 4, brick = 16 * row; };
 template <> struct BrickGeom<VV_VOXEL_U8>  { static constexpr uint32_t xlog2 = 2, bx = 4, row = 8, brick = 128; };
 enum { LAYOUT_LINEAR = 0, LAYOUT_LINEAR_BIG = 1, LAYOUT_BRICKED = 2, LAYOUT_ZPAIR = 3 };
 
@@ -348,8 +351,17 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
                 float f = __uint_as_float(((uint32_t)h & 0xffffu) | 0x3a000000u); C.a = {f, f}; C.b = C.a; C.c = C.a; C.d = C.a; return;
             }
 #endif
-            C.a = *(const float2u *)(L0 + (o0 + zi0)); C.b = *(const float2u *)(L0 + (o1 + zi0));
-            C.c = *(const float2u *)(L1 + (o0 + zi1)); C.d = *(const float2u *)(L1 + (o1 + zi1));
+            if constexpr (G::halo != 0) {
+                C.a = *(const float2u *)(L0 + (o0 + zi0)); C.b = *(const float2u *)(L0 + (o1 + zi0));
+                C.c = *(const float2u *)(L1 + (o0 + zi1)); C.d = *(const float2u *)(L1 + (o1 + zi1));
+            } else {
+                // whole-line bricks: voxel x+1 is the next dword, or the first of the same row in the next brick
+                const uint32_t dx = (ix & (G::bx - 1u)) == G::bx - 1u ? G::brick - (G::bx - 1u) * 4u : 4u;
+                const char *pa = L0 + (o0 + zi0), *pb = L0 + (o1 + zi0), *pc = L1 + (o0 + zi1), *pd = L1 + (o1 + zi1);
+                const float a0 = *(const float *)pa, b0 = *(const float *)pb, c0 = *(const float *)pc, d0 = *(const float *)pd;
+                const float a1 = *(const float *)(pa + dx), b1 = *(const float *)(pb + dx), c1 = *(const float *)(pc + dx), d1 = *(const float *)(pd + dx);
+                C.a = {a0, a1}; C.b = {b0, b1}; C.c = {c0, c1}; C.d = {d0, d1};
+            }
         } else {
             // the whole 8-byte row (voxels 4*(x>>2) .. +4, then padding) in one aligned load;
             // finish_corners shifts voxel x to byte 0 exactly as for the linear layout

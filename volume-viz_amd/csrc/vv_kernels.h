@@ -39,7 +39,8 @@ struct MarchArgs {
     int lds_reserve;            // march_kernel: dynamic LDS bytes reserved only to cap blocks per CU
     int unroll;                 // march_kernel: samples per loop trip (2 or 3)
     int lds_reserve_phong;      // march_phong_kernel: same occupancy cap (its own LDS is 5 KB + 9 KB per slab)
-    int phong_spb;              // march_phong_kernel: x-adjacent slabs per block (1, 2 or 4)
+    int phong_spb;              // march_phong_kernel: x-adjacent slabs per block (1 or 2)
+    int phong_compact;          // march_phong_kernel: refresh only the cache entries a compositing ray reads
     SweepArgs sweep;                   // sweep_kernel (vv_sweep.hip)
     StripMap strips;                   // march_kernel: strips of 8 pixel rows (n_strips of them)
     SlabMap slabs;                     // march_phong_kernel grid.y = n_regular + 1

@@ -294,7 +294,13 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 // SPB x-adjacent slabs per block (256 threads each, own apron, own `rad`, own LDS cache): a slab's footprint is 16
 // pixels wide, about one 128-byte line of voxels that mostly straddles two; neighbouring slabs marched by the same
 // block at the same time find each other's lines in L1 (measured: the one-slab form moves 2.8x the algorithmic bytes).
-template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB>
+//
+// COMPACT: the cache refresh (the gathers) is dealt to the lanes as (needed ray, quarter of its 32 entries) work items
+// instead of "every thread refreshes its own 32".  A ray's entries are needed in a chunk only if it or one of the four
+// rays that look at it composites in that chunk (the reference refreshes all 256: its apron corners, rays that have
+// terminated, rays that miss the volume and their far neighbours are refreshed and never read).  Values and addresses
+// of the entries that are read are unchanged, so frames stay bit-identical.
+template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB, bool COMPACT>
 __global__ __launch_bounds__(256 * SPB) void march_phong_kernel(FrameParams P, VolumeView V,
                                                           const float4 *__restrict__ tf, SlabMap M,
                                                           uint32_t *__restrict__ pixels,
@@ -306,13 +312,33 @@ __global__ __launch_bounds__(256 * SPB) void march_phong_kernel(FrameParams P, V
     __shared__ uint8_t cache_[SPB][kCacheDepth][256];
     __shared__ float q255[256];              // q / 255.f for every byte q, by the same IEEE division
     __shared__ int any_live;
-    const int tid = threadIdx.x & 255, sub = threadIdx.x >> 8;
+    // COMPACT: chunk start position and step of every ray, who needs a refresh, and the packed list of those
+    __shared__ float pos0_[COMPACT ? 6 : 1][COMPACT ? SPB * 256 : 1];
+    __shared__ uint8_t need_[COMPACT ? SPB * 256 : 1], mine_[(COMPACT && INSTR) ? SPB * 256 : 1];
+    __shared__ uint16_t list_[COMPACT ? SPB * 256 : 1];
+    __shared__ int wtot_[4 * SPB];
+    // thread -> (slab of the block, thread of the slab).  One slab per block: a wave is 16 x 4 threads of it.  Several:
+    // a wave is 32 x 2 threads across two x-adjacent slabs, so its gathers touch the same two or three whole lines per
+    // voxel row that march_kernel's 32 x 2 wave tiles do instead of 1-2 half-used ones (the slabs keep their own
+    // apron, `rad` and cache: only which lane marches which ray changes)
+    int tid, sub;
+    if (SPB == 1) { tid = threadIdx.x; sub = 0; }
+    else {
+        const int w = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
+        sub = (w % (SPB / 2)) * 2 + ((l & 31) >> 4);
+        tid = ((w / (SPB / 2)) * 2 + (l >> 5)) * 16 + (l & 15);
+    }
     float *red = red_[sub];
     uint8_t (*cache)[256] = cache_[sub];
     // XCD-aware order (speed only, as in march_kernel): linear block L runs on XCD L % 8; XCD k takes the
     // grid rows k, k+8, ... so that the slabs of one row, which share volume lines, share an L2
     const int nbxg = (P.nbx + SPB - 1) / SPB;
-    const int gx = ((int)blockIdx.x >> 3) % nbxg, gy = (((int)blockIdx.x >> 3) / nbxg) * 8 + ((int)blockIdx.x & 7);
+#ifndef VV_PHONG_BAND
+#define VV_PHONG_BAND 1
+#endif
+    constexpr int BAND = VV_PHONG_BAND;      // vertically adjacent slab rows per XCD, dispatched next to each other
+    const int j_ = (int)blockIdx.x >> 3;
+    const int gx = (j_ / BAND) % nbxg, gy = ((j_ / (BAND * nbxg)) * 8 + ((int)blockIdx.x & 7)) * BAND + j_ % BAND;
     if (gy > M.n_regular) return;                              // block-uniform, before any barrier
     stage_tf(lds_tf, tf);
     // kernel.cu:175-177 divides six cached bytes by 255.f per shaded sample; a correctly rounded
@@ -387,13 +413,82 @@ __global__ __launch_bounds__(256 * SPB) void march_phong_kernel(FrameParams P, V
     const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
     const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
 
+    const int g = sub * 256 + tid;                     // this thread's ray within the block
+    if (COMPACT) {
+        need_[g] = 0;
+        pos0_[3][g] = r.sdir.x; pos0_[4][g] = r.sdir.y; pos0_[5][g] = r.sdir.z;
+        __syncthreads();
+    }
     for (int chunk = 0; chunk < P.max_chunks; ++chunk) {
         bool mine = marching && !ert_done && dist < r.upper;
-        if (threadIdx.x == 0) any_live = 0;
-        __syncthreads();
-        if (mine) any_live = 1;
-        __syncthreads();
-        if (!any_live) break;
+        if (!COMPACT) {
+            if (threadIdx.x == 0) any_live = 0;
+            __syncthreads();
+            if (mine) any_live = 1;
+            __syncthreads();
+            if (!any_live) break;
+        }
+        if (COMPACT) {
+            constexpr int NT = 256 * SPB, NW = 4 * SPB;
+            {
+#pragma clang fp contract(off)
+                pos0_[0][g] = r.origin.x + r.dir.x * dist; pos0_[1][g] = r.origin.y + r.dir.y * dist; pos0_[2][g] = r.origin.z + r.dir.z * dist;
+            }
+            if (INSTR) mine_[g] = mine;
+            // need_ is all zero here (cleared before the loop, or by its readers in the last chunk, barriers in between)
+            if (mine) { const int b = sub * 256; need_[g] = 1; need_[b + nl] = 1; need_[b + nr] = 1; need_[b + nt] = 1; need_[b + nb] = 1; }
+            __syncthreads();
+            // pack the needed rays in thread order (neighbouring lanes keep neighbouring rays)
+            const bool nd = need_[g] != 0;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(nd);
+            const int wv = (int)threadIdx.x >> 6;
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if ((threadIdx.x & 63) == 0) wtot_[wv] = __builtin_popcountll(bal);
+            need_[g] = 0;                         // only this thread reads its flag
+            __syncthreads();
+            int off = 0, n = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const int c = wtot_[w]; off += w < wv ? c : 0; n += c; }
+            if (n == 0) break;                    // block-uniform
+            if (nd) list_[off + rank] = (uint16_t)g;
+            __syncthreads();
+            const int n_items = n * 4;
+            constexpr int PU = 4;
+            for (int base = 0; base < n_items; base += NT) {
+                const int item = base + (int)threadIdx.x;
+                if (item < n_items) {
+                    const int q = (item >= n) + (item >= 2 * n) + (item >= 3 * n);
+                    const int gg = list_[item - q * n];
+                    uint8_t (*cq)[256] = cache_[gg >> 8];
+                    const int tt = gg & 255;
+                    float px = pos0_[0][gg], py = pos0_[1][gg], pz = pos0_[2][gg];
+                    const float sx = pos0_[3][gg], sy = pos0_[4][gg], sz = pos0_[5][gg];
+                    for (int k = 0; k < q * 8; ++k) { px += sx; py += sy; pz += sz; }     // the reference's running sum (:139-141)
+                    const bool mk = INSTR && bricks && mine_[gg];
+#pragma unroll 1
+                    for (int i0 = q * 8; i0 < q * 8 + 8; i0 += PU) {
+                        float tx_[PU], ty_[PU], tz_[PU];
+                        typename CornerSel<VOXEL>::type C[PU];
+#pragma unroll
+                        for (int u = 0; u < PU; ++u) {
+                            tx_[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
+                            ty_[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
+                            tz_[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
+                            fetch_any<VOXEL, TEX8>(V, tx_[u], ty_[u], tz_[u], C[u]);
+                            px += sx; py += sy; pz += sz;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < PU; ++u) {
+                            const int i = i0 + u;
+                            cq[i][tt] = (uint8_t)classify_index<VOXEL>(C[u], tx_[u], ty_[u], tz_[u]);
+                            if (INSTR && mk && i >= 1 && i <= 30 && bounds_check(tx_[u], ty_[u], tz_[u])) mark_bricks(bricks, V, tx_[u], ty_[u], tz_[u]);
+                        }
+                    }
+                }
+            }
+            if (INSTR && threadIdx.x == 0) atomicAdd(counter + 1, (unsigned long long)n * kCacheDepth);   // entries refreshed
+        } else
         // rayMarch: every thread refreshes its 32 cache entries for this chunk  :125-145
         {
             float px, py, pz;
@@ -412,7 +507,12 @@ __global__ __launch_bounds__(256 * SPB) void march_phong_kernel(FrameParams P, V
 #endif
 #endif
             constexpr int PU = VV_PHONG_PU;
+#ifdef VV_X_PHONG_NOFETCH                // decomposition build (tools/decompose_phong.sh): no gathers, pixels are wrong
+            for (int i = 0; i < kCacheDepth; ++i) cache[i][tid] = (uint8_t)((tid * 7 + i * 13 + chunk) & 255);
+            for (int i0 = 0; i0 < 0; i0 += PU) {
+#else
             for (int i0 = 0; i0 < kCacheDepth; i0 += PU) {
+#endif
                 float tx_[PU], ty_[PU], tz_[PU];
                 typename CornerSel<VOXEL>::type C[PU];
 #pragma unroll
@@ -433,7 +533,17 @@ __global__ __launch_bounds__(256 * SPB) void march_phong_kernel(FrameParams P, V
             }
         }
         __syncthreads();
+#ifdef VV_X_PHONG_NOSHADE                // decomposition build: the gathers without the shading
         if (mine) {
+            uint32_t acc = 0;
+            for (int i = 1; i < kCacheDepth - 1; ++i) acc += cache[i][tid] + cache[i][nl];
+            res_r += (float)acc; res_a += 1e-4f;
+            if (res_a > P.ert_thr) ert_done = true;
+        }
+        if (false) {
+#else
+        if (mine) {
+#endif
             for (int i = 1; i < kCacheDepth - 1; ++i) {
 #pragma clang fp contract(off)
                 float vd = (float)i * r.sstep + dist;                                 // :254
@@ -512,20 +622,25 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
         hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 2>), grid, dim3(256), (size_t)a.lds_reserve, s,
                            a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
 }
-template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB>
+template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB, bool COMPACT>
 static void launch_phong_spb(const MarchArgs &a, hipStream_t s)
 {
     const int rows = a.slabs.n_regular + 1;                   // grid rows, dealt to the 8 XCDs round-robin
-    dim3 grid((unsigned)(((rows + 7) / 8) * 8 * ((a.P.nbx + SPB - 1) / SPB)));
-    hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR, SPB>), grid, dim3(256 * SPB), (size_t)a.lds_reserve_phong, s,
+    constexpr int BAND = VV_PHONG_BAND;
+    dim3 grid((unsigned)(((rows + 8 * BAND - 1) / (8 * BAND)) * 8 * BAND * ((a.P.nbx + SPB - 1) / SPB)));
+    hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR, SPB, COMPACT>), grid, dim3(256 * SPB), (size_t)a.lds_reserve_phong, s,
                        a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
 }
 template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 static void launch_phong(const MarchArgs &a, hipStream_t s)
 {
-    if (a.phong_spb >= 4) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 4>(a, s);
-    else if (a.phong_spb == 2) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 2>(a, s);
-    else launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 1>(a, s);
+    if (a.phong_compact) {
+        if (a.phong_spb == 2) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 2, true>(a, s);
+        else launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 1, true>(a, s);
+    } else {
+        if (a.phong_spb == 2) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 2, false>(a, s);
+        else launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 1, false>(a, s);
+    }
 }
 
 template <int SLICE, int VOXEL, bool TEX8>

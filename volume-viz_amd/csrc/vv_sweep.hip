@@ -332,8 +332,10 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
                     for (int j = 0; j < ng; ++j) {
 #pragma unroll 1
                         for (int rr = 0; rr < nrows; ++rr) {
+#ifndef VV_SWEEP_DUMMY_LOADER            // experiment build: the bookkeeping without the copies (rate of the consumers alone; pixels are wrong)
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
                                                              (__attribute__((address_space(3))) void *)(lds + lb), 16, 0, 0);
+#endif
                             gp += Sr; lb += pitch;
                         }
                         gp += gstep;
@@ -506,6 +508,10 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
 
         // ---- eight corners ----
         uint32_t idx;
+#ifdef VV_SWEEP_DUMMY_CONSUMER
+        // experiment build: consumers take their samples without reading the slices (pipeline rate of the loaders alone)
+        if (true) { idx = (uint32_t)(k0 & 255); } else
+#endif
         if (!tail) {
             const i2v T0 = lds_load_i2(&ctl->tab[k0 & (kTab - 1)]), T1 = lds_load_i2(&ctl->tab[(k0 + kmul) & (kTab - 1)]);
             const int x4 = (int)(ix << 2);
