@@ -485,6 +485,61 @@ def test_sweep_kernel_is_bit_identical(ctx, view, monkeypatch):
         assert n_got == n
 
 
+def _sweep_case(rng):
+    n = 4 * int(rng.integers(3, 18))
+    dims = (n, n, n) if rng.random() < 0.5 else (4 * int(rng.integers(3, 18)), int(rng.integers(12, 72)), int(rng.integers(12, 72)))
+    W = int(rng.choice([int(rng.integers(2, 260)), 29, 97, 193])); H = int(rng.choice([int(rng.integers(2, 200)), 29, 57]))
+    axis = int(rng.integers(0, 4))                                  # +z, -z, +y, -y
+    r = float(rng.uniform(2.6, 5.0)); t1, t2 = (float(v) for v in rng.uniform(-0.35, 0.35, size=2))
+    if axis < 2:
+        cam = vv.Camera(origin=(r * t1, r * t2, (-1.0 if axis == 0 else 1.0) * r), up=(0.0, 1.0, 0.0))
+    else:
+        cam = vv.Camera(origin=(r * t1, (-1.0 if axis == 2 else 1.0) * r, r * t2), up=(0.0, 0.0, 1.0))
+    step = float(rng.choice([1 / 16, 1 / 37, 1 / 64, 1 / 130]))
+    return dims, W, H, cam, step
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_sweep_kernel_seeded(ctx, seed, monkeypatch):
+    """Seeded cases for the slab sweep, like test_render_random_sweep but drawn (by rejection against the host-side
+    planner, vv_debug_plan_sweep) from what the sweep accepts: f32, unshaded, no cutting plane, 16-byte rows, eye
+    outside the cube roughly along +-y or +-z with a random tilt, samples at most 3 slices apart.  Random volume
+    shapes and content, tables, frame sizes, steps, filters, ERT modes and thresholds: frames and sample counts
+    equal the oracle's, and the instrumented build confirms the sweep kernel is what ran."""
+    monkeypatch.setenv("VV_SWEEP", "1")
+    rng = np.random.default_rng(7000 + seed)
+    for _ in range(64):
+        dims, W, H, cam, step = _sweep_case(rng)
+        if vv.plan_sweep(W, H, cam, step, vv.VOXEL_F32, dims)["enabled"]:
+            break
+    else:
+        pytest.fail("no case the planner accepts in 64 draws")
+    kind = seed % 3
+    vol = (O.draw_default_brain(*dims) if kind == 0 else O.noise_u8(*dims, int(rng.integers(1, 2**31))) if kind == 1
+           else rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)).astype(np.float32) / np.float32(255)
+    if rng.random() < 0.3:
+        vol = (vol * np.float32(1.3) - np.float32(0.1)).astype(np.float32)
+    if rng.random() < 0.5:
+        tf = vv.transfer_preset(int(rng.choice([vv.TF_ENGINE, vv.TF_HEAD, vv.TF_MRI])))
+    else:
+        tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
+        tf[:, 3] *= np.float32(rng.choice([0.03, 0.2, 1.0]))
+    o = dict(step=step, filter=int(rng.choice([vv.FILTER_TEX8, vv.FILTER_EXACT])),
+             ert_mode=int(rng.choice([vv.ERT_REFERENCE, vv.ERT_TRUE])), ert_threshold=float(rng.choice([0.95, 0.5, 0.999])))
+    ctx.load_volume(vol, tf)
+    got = ctx.render(W, H, cam, options=vv.make_options(count_samples=True, **o), fill=0x3C)
+    n_got = ctx.last_sample_count()
+    cnt = ctx.debug_counters()
+    want, n_want = O.render(vol, tf, W, H, cam, options=vv.make_options(**o), fill=0x3C)
+    what = f"sweep seed {seed}: {vol.shape} {W}x{H} eye {tuple(round(v, 2) for v in cam.origin)} {o}"
+    assert cnt[5] > 0, f"{what}: the planner accepted the frame but the sweep kernel staged nothing"
+    assert cnt[4] == 0 and cnt[7] == 0, f"{what}: {cnt[4]} samples outside the LDS images, error flags {cnt[7]:#x}"
+    assert_frames_close(got, want, what)
+    assert n_got == n_want, what
+    got2 = ctx.render(W, H, cam, options=vv.make_options(**o), fill=0x3C)                  # the uninstrumented build
+    assert np.array_equal(got2, want), what + " (uninstrumented)"
+
+
 @pytest.mark.parametrize("spb,compact", [(1, 0), (2, 0), (1, 1), (2, 1)])
 def test_phong_blocks_of_several_slabs_are_bit_identical(ctx, spb, compact, monkeypatch):
     """march_phong_kernel's launch forms (speed only): one or two x-adjacent slabs per block (each slab keeps its own
