@@ -53,6 +53,7 @@ struct vv_context {
     void *d_zpair = nullptr; bool zpair_valid = false; uint32_t zp_row = 0, zp_slab = 0; size_t zpair_bytes = 0;
     // transfer function
     float4 *d_tf = nullptr; bool tf_gray = false; bool have_tf = false;
+    bool tf_alpha_unit = false;          // every opacity of the table lies in [0, 1]: accumulated opacity never decreases
     // scratch
     float *d_rad = nullptr; size_t rad_cap = 0;
     uint8_t *d_frame = nullptr; size_t frame_cap = 0;
@@ -175,12 +176,14 @@ int vv_set_transfer_function(vv_context *c, const float tf[1024])
     HIPCHK(c, hipSetDevice(c->device));
     for (int i = 0; i < 1024; ++i)
         if (!std::isfinite(tf[i])) return fail(c, VV_ERR_INVALID, "vv_set_transfer_function: table entries must be finite");
-    bool gray = true;
+    bool gray = true, unit = true;
     for (int i = 0; i < 256; ++i)
         if (!(tf[4*i] == tf[4*i+1] && tf[4*i] == tf[4*i+2])) { gray = false; break; }
+    for (int i = 0; i < 256; ++i)
+        if (!(tf[4*i+3] >= 0.f && tf[4*i+3] <= 1.f)) { unit = false; break; }
     // pageable host memory: the copy is staged before hipMemcpy returns      kernel.cu:495-496
     HIPCHK(c, hipMemcpy(c->d_tf, tf, 1024 * sizeof(float), hipMemcpyHostToDevice));
-    c->tf_gray = gray; c->have_tf = true;
+    c->tf_gray = gray; c->tf_alpha_unit = unit; c->have_tf = true;
     return VV_OK;
 }
 
@@ -600,7 +603,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     int rb = 0, re = P.nby;
     int s_count = 1, s_index = 0, s_band = 4;
     P.step[0] = 1.f / (float)c->nx; P.step[1] = 1.f / (float)c->ny; P.step[2] = 1.f / (float)c->nz;   // :415
-    P.ert_thr = .95f; P.ert_true = 0;
+    P.ert_thr = .95f; P.ert_true = 0; P.alpha_unit = c->tf_alpha_unit;
     A.tex8 = true; A.instr = false;
     A.bricks = nullptr;
     if (opts) {
@@ -747,13 +750,11 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)
     A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f) ? 30000 : 13000);
     if (K.lds_reserve_phong >= 0 && K.lds_reserve_phong <= 146 * 1024) A.lds_reserve_phong = K.lds_reserve_phong;
-    // Two x-adjacent slabs per block (waves of 32 x 2 threads across both): measured with tools/ab_phong_cases.sh it
-    // wins only where the linear f32 volume is far beyond the caches and sparsely sampled (C3 + Phong 2.28 -> 2.16 ms,
-    // brain + engine table 2.21 -> 2.00) and loses 5-25 % everywhere else (cache-resident volumes, u8, bricks, the
-    // dense frames of the multi-GPU configurations, the 32 GiB volume), so that is the only case that uses it.
-    A.phong_spb = (!use_bricks && c->vtype == VV_VOXEL_F32 && beyond_caches && c->vol_bytes <= (8ull << 30) && density > 3.5f) ? 2 : 1;
+    // Two x-adjacent slabs per block (waves of 32 x 2 threads across both; VV_PHONG_SPB=2): with the depth-limited
+    // refresh it wins 2 % on C3 + Phong and loses 1-25 % on everything else (tools/ab_phong_cases.sh): opt-in.
+    A.phong_spb = 1;
     if (K.phong_spb == 1 || K.phong_spb == 2) A.phong_spb = K.phong_spb;
-    // Cache refresh dealt out as (needed ray, quarter) items: 19 % fewer gathers on C3 + Phong, 4-6 % slower (opt-in)
+    // Cache refresh dealt out as (needed ray, quarter) items: 5 % fewer gathers on C3 + Phong, 4-6 % slower (opt-in)
     A.phong_compact = K.phong_compact == 1;
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;

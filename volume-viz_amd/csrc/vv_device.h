@@ -83,6 +83,7 @@ struct FrameParams {
     float tan_fov_x, tan_fov_y;   // kernel.cu:221-222 (computed in double on the host)
     float ert_thr;
     int   ert_true;
+    int   alpha_unit;             // every table opacity in [0, 1] (a ray past the threshold stays past it)
     int   max_chunks;             // hard bound on the chunk loop (every wave exits)
     // ray source
     int ray_mode, quantize8;
@@ -90,6 +91,9 @@ struct FrameParams {
     float side[3], up[3], look[3];   // orthonormal camera basis (camera.cpp:78-91)
     float tan_half_x, tan_half_y;    // tan(fovY/2)*aspect, tan(fovY/2)
 };
+
+__device__ __forceinline__ int wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
 
 // ---------------------------------------------------------------------------
 // strict (uncontracted) helpers for per-ray set-up

@@ -301,7 +301,15 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 // terminated, rays that miss the volume and their far neighbours are refreshed and never read).  Values and addresses
 // of the entries that are read are unchanged, so frames stay bit-identical.
 template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB, bool COMPACT>
-__global__ __launch_bounds__(256 * SPB) void march_phong_kernel(FrameParams P, VolumeView V,
+// Registers: on the linear layout up to 4 GiB the kernel is compiled for 5 waves per SIMD (83-85 VGPRs: the volumes that
+// live in the caches want 5 blocks per CU; C1 0.196 -> 0.174 ms, 256^3 1.36 -> 1.28); the variants for volumes beyond
+// 4 GiB and for the bricked copy run 2-3 blocks per CU and are 2-7 % faster with the 106 VGPRs the compiler takes by itself.
+#if defined(VV_BIG_VOLUME) || defined(VV_BRICKED)
+#define VV_PHONG_OCC
+#else
+#define VV_PHONG_OCC __attribute__((amdgpu_waves_per_eu(5)))
+#endif
+__global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(FrameParams P, VolumeView V,
                                                           const float4 *__restrict__ tf, SlabMap M,
                                                           uint32_t *__restrict__ pixels,
                                                           unsigned long long *__restrict__ counter,
@@ -421,12 +429,39 @@ __global__ __launch_bounds__(256 * SPB) void march_phong_kernel(FrameParams P, V
     }
     for (int chunk = 0; chunk < P.max_chunks; ++chunk) {
         bool mine = marching && !ert_done && dist < r.upper;
+        // How deep this chunk's cache has to be: a compositing ray reads its entries 0 .. n+1 and its neighbours' 1 .. n,
+        // n = the samples of the chunk before `vd > upper` (:254).  A ray whose opacity already passed the threshold (it
+        // keeps compositing one sample per chunk, pin 4) reads entries 0 .. 2 only: with every table opacity in [0, 1]
+        // the accumulated opacity cannot fall back under the threshold (res_a <= 1 stays true in float arithmetic:
+        // fl(r + fl(c * fl(1 - r))) <= 1 for r, c in [0, 1]).  The block refreshes the deepest need of its rays -- the
+        // reference refreshes all 32 always (:125-145); entries nobody reads are not observable.
+        int depth = kCacheDepth;
         if (!COMPACT) {
+            int d = 0;
+            if (mine) {
+#pragma clang fp contract(off)
+                if (P.alpha_unit && res_a > P.ert_thr) d = 3;
+                else if (!(30.f * r.sstep + dist > r.upper)) d = kCacheDepth;
+                else {
+                    int n = 0;
+#pragma unroll 1
+                    for (int i = 1; i < kCacheDepth - 1; ++i) { const float vd = (float)i * r.sstep + dist; if (vd > r.upper) break; n = i; }
+                    d = n + 2;
+                }
+            }
             if (threadIdx.x == 0) any_live = 0;
             __syncthreads();
-            if (mine) any_live = 1;
+            // wave maximum: nearly always decided by two ballots (some ray at full depth, or every ray past the threshold)
+            {
+                const bool full = __builtin_amdgcn_ballot_w64(d == kCacheDepth) != 0ull, deep = __builtin_amdgcn_ballot_w64(d > 3) != 0ull;
+                if (full) d = kCacheDepth;
+                else if (!deep) d = __builtin_amdgcn_ballot_w64(d != 0) != 0ull ? 3 : 0;
+                else d = wave_max_i(d);
+            }
+            if ((threadIdx.x & 63) == 0 && d) atomicMax(&any_live, d);
             __syncthreads();
-            if (!any_live) break;
+            depth = any_live;
+            if (!depth) break;
         }
         if (COMPACT) {
             constexpr int NT = 256 * SPB, NW = 4 * SPB;
@@ -488,6 +523,7 @@ __global__ __launch_bounds__(256 * SPB) void march_phong_kernel(FrameParams P, V
                 }
             }
             if (INSTR && threadIdx.x == 0) atomicAdd(counter + 1, (unsigned long long)n * kCacheDepth);   // entries refreshed
+            if (INSTR && threadIdx.x == 0) atomicAdd(counter + 8 + min((n - 1) / (32 * SPB), 7), 1ull);         // histogram of needed rays per chunk
         } else
         // rayMarch: every thread refreshes its 32 cache entries for this chunk  :125-145
         {
@@ -511,25 +547,30 @@ __global__ __launch_bounds__(256 * SPB) void march_phong_kernel(FrameParams P, V
             for (int i = 0; i < kCacheDepth; ++i) cache[i][tid] = (uint8_t)((tid * 7 + i * 13 + chunk) & 255);
             for (int i0 = 0; i0 < 0; i0 += PU) {
 #else
-            for (int i0 = 0; i0 < kCacheDepth; i0 += PU) {
+            for (int i0 = 0; i0 < 1; i0 += PU) {
 #endif
-                float tx_[PU], ty_[PU], tz_[PU];
-                typename CornerSel<VOXEL>::type C[PU];
+                auto refresh = [&](const int i0) {
+                    float tx_[PU], ty_[PU], tz_[PU];
+                    typename CornerSel<VOXEL>::type C[PU];
 #pragma unroll
-                for (int u = 0; u < PU; ++u) {
-                    tx_[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
-                    ty_[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
-                    tz_[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-                    fetch_any<VOXEL, TEX8>(V, tx_[u], ty_[u], tz_[u], C[u]);
-                    px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int u = 0; u < PU; ++u) {
+                        tx_[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
+                        ty_[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
+                        tz_[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
+                        fetch_any<VOXEL, TEX8>(V, tx_[u], ty_[u], tz_[u], C[u]);
+                        px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < PU; ++u) {
-                    const int i = i0 + u;
-                    cache[i][tid] = (uint8_t)classify_index<VOXEL>(C[u], tx_[u], ty_[u], tz_[u]);
-                    if (INSTR && bricks && mine && i >= 1 && i <= 30 && bounds_check(tx_[u], ty_[u], tz_[u])) mark_bricks(bricks, V, tx_[u], ty_[u], tz_[u]);
-                }
+                    for (int u = 0; u < PU; ++u) {
+                        const int i = i0 + u;
+                        cache[i][tid] = (uint8_t)classify_index<VOXEL>(C[u], tx_[u], ty_[u], tz_[u]);
+                        if (INSTR && bricks && mine && i >= 1 && i <= 30 && bounds_check(tx_[u], ty_[u], tz_[u])) mark_bricks(bricks, V, tx_[u], ty_[u], tz_[u]);
+                    }
+                };
+                // the full depth keeps its compile-time trip count (the short form alone cost cache-resident volumes 5-13 %)
+                if (depth == kCacheDepth) { for (int j0 = 0; j0 < kCacheDepth; j0 += PU) refresh(j0); }
+                else { for (int j0 = 0; j0 < depth; j0 += PU) refresh(j0); }
             }
         }
         __syncthreads();

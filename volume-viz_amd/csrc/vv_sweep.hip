@@ -80,8 +80,6 @@ __device__ __forceinline__ int wave_min_fast(int v)   // uniform result
 }
 
 __device__ __forceinline__ bool any_(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-__device__ __forceinline__ int wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
 
 // volatile vector loads / stores in the LDS address space (through a generic pointer hipcc falls back to flat_load
 // with a full s_waitcnt: hundreds of cycles per access)
