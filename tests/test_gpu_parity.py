@@ -540,15 +540,14 @@ def test_sweep_kernel_seeded(ctx, seed, monkeypatch):
     assert np.array_equal(got2, want), what + " (uninstrumented)"
 
 
-@pytest.mark.parametrize("spb,compact,fused", [(1, 0, 0), (2, 0, 0), (1, 1, 0), (2, 1, 0), (1, 0, 1)])
-def test_phong_blocks_of_several_slabs_are_bit_identical(ctx, spb, compact, fused, monkeypatch):
+@pytest.mark.parametrize("spb,compact", [(1, 0), (2, 0), (1, 1), (2, 1)])
+def test_phong_blocks_of_several_slabs_are_bit_identical(ctx, spb, compact, monkeypatch):
     """march_phong_kernel's launch forms (speed only): one or two x-adjacent slabs per block (each slab keeps its own
     apron, radius and sample cache), and the cache refresh either by every thread for its own ray or dealt out as
     (needed ray, quarter) work items.  The sweep's cases with Phong forced on, frame widths that leave ghost slabs at
     the row's end, W == 1 (mod 14), shards, every layout, instrumented and not -- same frames, same sample counts."""
     monkeypatch.setenv("VV_PHONG_SPB", str(spb))
     monkeypatch.setenv("VV_PHONG_COMPACT", str(compact))
-    monkeypatch.setenv("VV_PHONG_FUSED", str(fused))      # refresh of chunk c + 1 interleaved with the shading of chunk c
     for seed in range(0, 48, 5):
         vol, tf, W, H, cam, sp, _, o = _random_case(seed)
         ctx.load_volume(vol, tf)

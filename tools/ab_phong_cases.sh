@@ -1,14 +1,12 @@
 #!/bin/bash
-# A/B: one vs two slabs per Phong block (VV_PHONG_SPB) and the fused form (VV_PHONG_FUSED) over volume sizes, views, voxel types and configurations
+# A/B: one vs two slabs per Phong block (VV_PHONG_SPB) over volume sizes, views, voxel types and configurations
 mkdir -p gpurun_out
 run() { # label, args...
   local label=$1; shift
   local out=""
-  for spb in 1 2 fused; do
-    local f=0 sp=$spb
-    if [ $spb = fused ]; then f=1; sp=1; fi
-    local ms=$(VV_PHONG_FUSED=$f VV_PHONG_SPB=$sp VV_BENCH_NO_EXTRA=1 timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --phong "$@" 2>/dev/null | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
-    out="$out $spb=$ms"
+  for spb in 1 2; do
+    local ms=$(VV_PHONG_SPB=$spb VV_BENCH_NO_EXTRA=1 timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --phong "$@" 2>/dev/null | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
+    out="$out spb$spb=$ms"
   done
   echo "$label:$out"
 }

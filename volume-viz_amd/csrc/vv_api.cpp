@@ -22,7 +22,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, wstaged = 0, sweep = -1, sweep_trace = 0, force_big = 0;
-    int phong_spb = -1, phong_compact = -1, phong_fused = -1;
+    int phong_spb = -1, phong_compact = -1;
     int sw_nl = -1, sw_wx = -1, sw_wy = -1, sw_group = -1, sw_depth = -1, sw_lead = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
@@ -32,7 +32,6 @@ struct vv_knobs {
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1); wstaged = geti("VV_WSTAGED", 0);
         phong_spb = geti("VV_PHONG_SPB", -1);
         phong_compact = geti("VV_PHONG_COMPACT", -1);
-        phong_fused = geti("VV_PHONG_FUSED", -1);
         sw_nl = geti("VV_SWEEP_NL", -1); sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_group = geti("VV_SWEEP_GROUP", -1);
         sw_depth = geti("VV_SWEEP_DEPTH", -1); sw_lead = geti("VV_SWEEP_LEAD", -1); sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
@@ -757,7 +756,6 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (K.phong_spb == 1 || K.phong_spb == 2) A.phong_spb = K.phong_spb;
     // Cache refresh dealt out as (needed ray, quarter) items: 5 % fewer gathers on C3 + Phong, 4-6 % slower (opt-in)
     A.phong_compact = K.phong_compact == 1;
-    A.phong_fused = K.phong_fused == 1;
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
     int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));

@@ -40,7 +40,6 @@ struct MarchArgs {
     int unroll;                 // march_kernel: samples per loop trip (2 or 3)
     int lds_reserve_phong;      // march_phong_kernel: same occupancy cap (its own LDS is 5 KB + 9 KB per slab)
     int phong_spb;              // march_phong_kernel: x-adjacent slabs per block (1 or 2)
-    int phong_fused;            // march_phong_kernel: refresh of chunk c + 1 interleaved with the shading of chunk c
     int phong_compact;          // march_phong_kernel: refresh only the cache entries a compositing ray reads
     SweepArgs sweep;                   // sweep_kernel (vv_sweep.hip)
     StripMap strips;                   // march_kernel: strips of 8 pixel rows (n_strips of them)

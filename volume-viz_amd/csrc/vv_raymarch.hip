@@ -300,12 +300,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 // rays that look at it composites in that chunk (the reference refreshes all 256: its apron corners, rays that have
 // terminated, rays that miss the volume and their far neighbours are refreshed and never read).  Values and addresses
 // of the entries that are read are unchanged, so frames stay bit-identical.
-//
-// FUSED (one slab per block): the refresh of chunk c + 1 and the shading of chunk c run in the same loop, four cache
-// entries and four samples at a time, on two cache buffers -- a wave's gathers are in flight while it shades, and a
-// chunk costs three barriers instead of four.  The next chunk's depth is taken from the state *before* this chunk is
-// shaded (a ray can only need less afterwards), so more may be refreshed than is read, never less.
-template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB, bool COMPACT, bool FUSED>
+template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB, bool COMPACT>
 // Registers: on the linear layout up to 4 GiB the kernel is compiled for 5 waves per SIMD (83-85 VGPRs: the volumes that
 // live in the caches want 5 blocks per CU; C1 0.196 -> 0.174 ms, 256^3 1.36 -> 1.28); the variants for volumes beyond
 // 4 GiB and for the bricked copy run 2-3 blocks per CU and are 2-7 % faster with the 106 VGPRs the compiler takes by itself.
@@ -322,10 +317,9 @@ __global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(Fra
 {
     __shared__ float4 lds_tf[256];
     __shared__ float red_[SPB][256];
-    static_assert(!FUSED || (SPB == 1 && !COMPACT), "the fused form is one slab per block");
-    __shared__ uint8_t cache_[FUSED ? 2 : SPB][kCacheDepth][256];
+    __shared__ uint8_t cache_[SPB][kCacheDepth][256];
     __shared__ float q255[256];              // q / 255.f for every byte q, by the same IEEE division
-    __shared__ int any_live, any2[2];
+    __shared__ int any_live;
     // COMPACT: chunk start position and step of every ray, who needs a refresh, and the packed list of those
     __shared__ float pos0_[COMPACT ? 6 : 1][COMPACT ? SPB * 256 : 1];
     __shared__ uint8_t need_[COMPACT ? SPB * 256 : 1], mine_[(COMPACT && INSTR) ? SPB * 256 : 1];
@@ -433,119 +427,6 @@ __global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(Fra
         pos0_[3][g] = r.sdir.x; pos0_[4][g] = r.sdir.y; pos0_[5][g] = r.sdir.z;
         __syncthreads();
     }
-    if constexpr (FUSED) {
-        float dist_n = r.dist0;                    // start of the chunk that is being refreshed (chunk c + 1)
-        auto need_depth = [&](bool live, float d0) -> int {
-#pragma clang fp contract(off)
-            if (!live) return 0;
-            if (P.alpha_unit && res_a > P.ert_thr) return 3;
-            if (!(30.f * r.sstep + d0 > r.upper)) return kCacheDepth;
-            int n = 0;
-#pragma unroll 1
-            for (int i = 1; i < kCacheDepth - 1; ++i) { const float vd = (float)i * r.sstep + d0; if (vd > r.upper) break; n = i; }
-            return n + 2;
-        };
-        auto wave_depth = [&](int d) -> int {
-            const bool full = __builtin_amdgcn_ballot_w64(d == kCacheDepth) != 0ull, deep = __builtin_amdgcn_ballot_w64(d > 3) != 0ull;
-            if (full) return kCacheDepth;
-            if (!deep) return __builtin_amdgcn_ballot_w64(d != 0) != 0ull ? 3 : 0;
-            return wave_max_i(d);
-        };
-        for (int c = -1; c < P.max_chunks; ++c) {
-            const bool mine = c >= 0 && marching && !ert_done && dist < r.upper;
-            const bool mine_n = c + 1 < P.max_chunks && marching && !ert_done && dist_n < r.upper;      // before chunk c is shaded
-            const int dc = wave_depth(need_depth(mine, dist)), dn = wave_depth(need_depth(mine_n, dist_n));
-            if (threadIdx.x == 0) { any2[0] = 0; any2[1] = 0; }
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) { if (dc) atomicMax(&any2[0], dc); if (dn) atomicMax(&any2[1], dn); }
-            __syncthreads();
-            const int Dc = any2[0], Dn = any2[1];
-            if (c >= 0 ? Dc == 0 : Dn == 0) break;                        // block-uniform; needs only shrink with c
-            uint8_t (*cur)[256] = cache_[c & 1], (*nxt)[256] = cache_[(c + 1) & 1];
-            float px, py, pz;
-            {
-#pragma clang fp contract(off)
-                px = r.origin.x + r.dir.x * dist_n; py = r.origin.y + r.dir.y * dist_n; pz = r.origin.z + r.dir.z * dist_n;
-            }
-            bool active = mine;
-            const int last_i = c >= 0 ? min(Dc - 2, kCacheDepth - 2) : 0;          // deepest sample any ray composites in chunk c
-            constexpr int PU = 4;
-#pragma unroll 1
-            for (int i0 = 0; i0 < kCacheDepth; i0 += PU) {
-                const bool do_ref = i0 < Dn, do_shade = i0 + 1 <= last_i;
-                if (!do_ref && !do_shade) break;
-                float tx_[PU], ty_[PU], tz_[PU];
-                typename CornerSel<VOXEL>::type C[PU];
-                if (do_ref) {
-#pragma unroll
-                    for (int u = 0; u < PU; ++u) {
-                        tx_[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
-                        ty_[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
-                        tz_[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-                        fetch_any<VOXEL, TEX8>(V, tx_[u], ty_[u], tz_[u], C[u]);
-                        px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (do_shade) {
-#pragma unroll 1
-                    for (int i = i0 + 1; i <= min(i0 + PU, kCacheDepth - 2); ++i) {
-#pragma clang fp contract(off)
-                        if (!active) break;
-                        float vd = (float)i * r.sstep + dist;                                 // :254
-                        if (vd > r.upper) { active = false; break; }
-                        if (INSTR) executed++;
-                        uint32_t s = cur[i][tid];
-                        float4 e = lds_tf[s];
-                        float cr = e.x, cg = e.y, cb = e.z, ca = e.w;
-                        if (ca > kEps) {                                                      // :164 (phong is on)
-                            const uint32_t qf = cur[i - 1][tid], qa = cur[i + 1][tid];
-                            const uint32_t ql = cur[i][nl], qr = cur[i][nr], qt = cur[i][nt], qb = cur[i][nb];
-                            float direct = 0.f;
-                            if (!(qr == ql && qt == qb && qa == qf)) {
-                                float f = q255[qf], a = q255[qa], l = q255[ql], rr = q255[qr], t = q255[qt], b = q255[qb];
-                                float gx = (rr - l) / (P.tan_fov_x * vd), gy = (t - b) / (P.tan_fov_y * vd),
-                                      gz = (a - f) / (r.sstep * 2.f);                         // :175-178, :259-263
-                                if (gx != 0.f && gy != 0.f && gz != 0.f) {
-                                    float inv = 1.0f / sqrtf(gx * gx + gy * gy + gz * gz);
-                                    gx *= inv; gy *= inv; gz *= inv;
-                                }
-                                direct = (gx * -1.f + gy * -1.f + gz * 1.f) * 0.3f;           // :183
-                                direct = fmaxf(0.f, fminf(direct, 0.3f));
-                            }
-                            cr = cr * 0.7f + direct; cg = cg * 0.7f + direct; cb = cb * 0.7f + direct;
-                        }
-                        if (SLICE == SLICE_PLANE) {
-                            float vx = r.origin.x + r.dir.x * vd, vy = r.origin.y + r.dir.y * vd, vz = r.origin.z + r.dir.z * vd;
-                            float d = fabsf(sn.x * (vx - sp.x) + sn.y * (vy - sp.y) + sn.z * (vz - sp.z));
-                            if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
-                        }
-                        if (ca > kEps) {
-                            float bf = ca * (1.f - res_a);
-                            res_r = res_r + cr * bf; res_g = res_g + cg * bf; res_b = res_b + cb * bf; res_a = res_a + bf;
-                        }
-                        if (res_a > P.ert_thr) { if (P.ert_true) ert_done = true; active = false; break; }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (do_ref) {
-#pragma unroll
-                    for (int u = 0; u < PU; ++u) {
-                        const int i = i0 + u;
-                        nxt[i][tid] = (uint8_t)classify_index<VOXEL>(C[u], tx_[u], ty_[u], tz_[u]);
-                        if (INSTR && bricks && mine_n && i >= 1 && i <= 30 && bounds_check(tx_[u], ty_[u], tz_[u])) mark_bricks(bricks, V, tx_[u], ty_[u], tz_[u]);
-                    }
-                }
-            }
-            __syncthreads();      // chunk c + 1 is complete, chunk c's buffer may be rewritten
-            if (c >= 0) dist = dist_n;
-            {
-#pragma clang fp contract(off)
-                dist_n = (c >= 0 ? dist : r.dist0) + r.sstep * kChunkSteps;
-            }
-            if (c < 0) dist = r.dist0;
-        }
-    } else
     for (int chunk = 0; chunk < P.max_chunks; ++chunk) {
         bool mine = marching && !ert_done && dist < r.upper;
         // How deep this chunk's cache has to be: a compositing ray reads its entries 0 .. n+1 and its neighbours' 1 .. n,
@@ -782,25 +663,24 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
         hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 2>), grid, dim3(256), (size_t)a.lds_reserve, s,
                            a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
 }
-template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB, bool COMPACT, bool FUSED>
+template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB, bool COMPACT>
 static void launch_phong_spb(const MarchArgs &a, hipStream_t s)
 {
     const int rows = a.slabs.n_regular + 1;                   // grid rows, dealt to the 8 XCDs round-robin
     constexpr int BAND = VV_PHONG_BAND;
     dim3 grid((unsigned)(((rows + 8 * BAND - 1) / (8 * BAND)) * 8 * BAND * ((a.P.nbx + SPB - 1) / SPB)));
-    hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR, SPB, COMPACT, FUSED>), grid, dim3(256 * SPB), (size_t)a.lds_reserve_phong, s,
+    hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR, SPB, COMPACT>), grid, dim3(256 * SPB), (size_t)a.lds_reserve_phong, s,
                        a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
 }
 template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 static void launch_phong(const MarchArgs &a, hipStream_t s)
 {
-    if (a.phong_fused) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 1, false, true>(a, s);
-    else if (a.phong_compact) {
-        if (a.phong_spb == 2) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 2, true, false>(a, s);
-        else launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 1, true, false>(a, s);
+    if (a.phong_compact) {
+        if (a.phong_spb == 2) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 2, true>(a, s);
+        else launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 1, true>(a, s);
     } else {
-        if (a.phong_spb == 2) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 2, false, false>(a, s);
-        else launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 1, false, false>(a, s);
+        if (a.phong_spb == 2) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 2, false>(a, s);
+        else launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 1, false>(a, s);
     }
 }
 
