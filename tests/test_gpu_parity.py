@@ -485,6 +485,36 @@ def test_sweep_kernel_is_bit_identical(ctx, view, monkeypatch):
         assert n_got == n
 
 
+@pytest.mark.parametrize("phong", [False, True])
+def test_tables_with_opacity_outside_unit_interval(ctx, phong, monkeypatch):
+    """A table whose opacities exceed 1 (or are negative) makes the accumulated opacity non-monotone: a ray that passed
+    the ERT threshold can fall back under it, and the reference's per-sample test (kernel.cu:272-274) then composites more
+    than one sample in later chunks.  The kernels' one-sample-per-chunk shortcuts (pin 4, the depth-limited Phong
+    refresh) apply only to tables with opacities in [0, 1]; every layout and the sweep kernel must match the oracle."""
+    rng = np.random.default_rng(4242)
+    vol = O.noise_u8(40, 36, 44, 11).astype(np.float32) / np.float32(255)
+    for k, (lo, hi) in enumerate(((0.0, 2.5), (-0.5, 1.8), (0.0, 1.0))):
+        tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
+        tf[:, 3] = rng.uniform(lo, hi, 256).astype(np.float32)
+        for env in ({}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_SWEEP": "1"}, {"VV_WSTAGED": "1"}):
+            for name in ("VV_BRICKED", "VV_ZPAIR", "VV_SWEEP", "VV_WSTAGED"):
+                monkeypatch.delenv(name, raising=False)
+            for name, val in env.items():
+                monkeypatch.setenv(name, val)
+            ctx.load_volume(vol, tf)
+            for cam in (_cam("a"), _cam("b")):
+                for thr in (0.5, 0.95):
+                    o = dict(step=1 / 64, ert_threshold=thr, ert_mode=vv.ERT_REFERENCE)
+                    got = ctx.render(120, 90, cam, phong=phong, options=vv.make_options(count_samples=True, **o), fill=0x21)
+                    n_got = ctx.last_sample_count()
+                    want, n = O.render(vol, tf, 120, 90, cam, phong=phong, options=vv.make_options(**o), fill=0x21)
+                    what = f"opacity in [{lo}, {hi}] {env} phong={phong} thr={thr}"
+                    assert n_got == n, what
+                    assert_frames_close(got, want, what)
+                    got2 = ctx.render(120, 90, cam, phong=phong, options=vv.make_options(**o), fill=0x21)
+                    assert np.array_equal(got2, want), what + " (uninstrumented)"
+
+
 def _sweep_case(rng):
     n = 4 * int(rng.integers(3, 18))
     dims = (n, n, n) if rng.random() < 0.5 else (4 * int(rng.integers(3, 18)), int(rng.integers(12, 72)), int(rng.integers(12, 72)))

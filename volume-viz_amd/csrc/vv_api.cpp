@@ -261,6 +261,7 @@ int vv_debug_plan_sweep(int W, int H, const camera_params *cam, const vv_ray_sou
     P.W = W; P.H = H;
     P.nbx = W / kSlab + ((W % kSlab) ? 1 : 0); P.nby = H / kSlab + ((H % kSlab) ? 1 : 0);
     P.rb = 0; P.re = P.nby; P.band = 4; P.count = 1; P.index = 0;
+    P.alpha_unit = 1;                 // (the planner's answer for a table with opacities in [0, 1])
     P.slice_type = slice_type;
     for (int a = 0; a < 3; ++a) {
         if (!(cam->scale[a] > 0.f)) return VV_ERR_INVALID;
@@ -790,7 +791,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         // view: 8.8 ms vs 6.8 ms), so it is opt-in (VV_WSTAGED=1) and kept as the base for the
         // staged design of DESIGN.md section 4.  It needs 16-byte aligned rows and <= 4 GiB.
         bool wst = false;
-        if (K.wstaged) wst = (A.V.row_bytes % 16u) == 0 && !A.V.big;
+        if (K.wstaged) wst = (A.V.row_bytes % 16u) == 0 && !A.V.big && c->tf_alpha_unit;
         // Slab sweep (vv_sweep.hip): the volume streamed through LDS by dedicated loader waves.
         bool sweep = false;
         if (K.sweep >= 0) sweep = K.sweep != 0;

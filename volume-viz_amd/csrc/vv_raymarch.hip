@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
     // a lane whose own `while (dist < upper)` has ended simply has n == 0.
     for (int chunk = 0; chunk < P.max_chunks && __any(dist < r.upper); ++chunk) {
         int n = chunk_count(dist, r.upper, r.sstep);
-        if (ert) n = min(n, 1);          // reference ERT: later chunks composite sample 1 only
+        // reference ERT: a ray past the threshold composites sample 1 of every later chunk and breaks again (:272-274)
+        // -- as long as its opacity cannot fall back under the threshold, i.e. for tables with opacities in [0, 1];
+        // otherwise every chunk runs the reference's per-sample test in full
+        if (ert && P.alpha_unit) n = min(n, 1);
         float px, py, pz;
         {
 #pragma clang fp contract(off)

@@ -672,6 +672,7 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     const FrameParams &P = A.P;
     const VolumeView &V = A.V;
     if (A.phong || A.V_type != VV_VOXEL_F32 || P.slice_type != SLICE_NONE) VV_NO("shaded, u8 or cutting plane");
+    if (!P.alpha_unit) VV_NO("table opacities outside [0, 1]");       // the one-sample tail after early termination assumes monotone opacity
     if (P.ray_mode != VV_RAYS_ANALYTIC || P.quantize8) VV_NO("rays from images / quantised");
     if ((V.row_bytes & 15u) || (V.slice_bytes & 15u) || ((uintptr_t)V.data & 15u)) VV_NO("rows not 16-byte aligned");
     if (!(P.step[0] == P.step[1] && P.step[1] == P.step[2])) VV_NO("anisotropic step");      // samples of a chunk must stay on the ray's line
