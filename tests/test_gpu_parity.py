@@ -515,6 +515,46 @@ def test_tables_with_opacity_outside_unit_interval(ctx, phong, monkeypatch):
                     assert np.array_equal(got2, want), what + " (uninstrumented)"
 
 
+def test_sharded_phong_frame_whose_height_is_1_mod_14(ctx):
+    """H == 1 (mod 14): the reference's last slab row only re-writes pixel row H - 2 (pin 10).  A sharded grid walks
+    whole bands of slab rows and must not march that row a second time as a regular one: same pixels, but the samples
+    were counted twice (found by tools/fuzz_wild.py)."""
+    vol = O.noise_u8(17, 9, 12, 5)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    for W, H, shard in ((29, 29, (8, 4, 0)), (30, 15, (8, 4, 0)), (16, 29, (4, 4, 0)), (46, 43, (4, 2, 1)), (20, 57, (4, 2, 0))):
+        o = vv.make_options(step=1 / 64, count_samples=True, shard=shard)
+        got = ctx.render(W, H, _cam("b"), phong=True, options=o, fill=0x5A)
+        n_got = ctx.last_sample_count()
+        want, n = O.render(vol, tf, W, H, _cam("b"), phong=True, options=o, fill=0x5A)
+        assert_frames_close(got, want, f"{W}x{H} shard {shard}")
+        assert n_got == n, f"{W}x{H} shard {shard}: {n_got} samples counted, the oracle executes {n}"
+
+
+@pytest.mark.parametrize("first", range(0, 200, 50))
+def test_wild_fuzz_subset(ctx, first, monkeypatch):
+    """200 cases of tools/fuzz_wild.py (degenerate volume shapes, tables with colours and opacities outside [0, 1], eyes
+    inside the cube, extreme scales, steps and thresholds, shards; every layout and launch form in turn): frames and
+    sample counts equal the oracle's.  The tool itself ran seeds 0..2999 on MI355X without a mismatch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_wild", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_wild.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    for seed in range(first, first + 50):
+        for k in fz.KNOBS:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in fz.ENVS[seed % len(fz.ENVS)].items():
+            monkeypatch.setenv(k, v)
+        vol, tf, W, H, cam, sp, phong, o = fz.case(seed)
+        ctx.load_volume(vol, tf)
+        opts = vv.make_options(**o)
+        got = ctx.render(W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
+        n_got = ctx.last_sample_count() if o["count_samples"] else None
+        want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
+        what = f"wild seed {seed}: {vol.shape} {vol.dtype} {W}x{H} phong={phong} {o}"
+        assert_frames_close(got, want, what)
+        assert n_got is None or n_got == n, what
+
+
 def _sweep_case(rng):
     n = 4 * int(rng.integers(3, 18))
     dims = (n, n, n) if rng.random() < 0.5 else (4 * int(rng.integers(3, 18)), int(rng.integers(12, 72)), int(rng.integers(12, 72)))

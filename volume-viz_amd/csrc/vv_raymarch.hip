@@ -367,6 +367,9 @@ __global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(Fra
     if (gy == M.n_regular) { if (!P.conflict_y) return; by = P.nby - 1; }
     else by = M.r0 + (gy / M.band) * M.band_stride + (gy % M.band);
     if (by >= P.nby) return;                                   // block-uniform
+    // a sharded grid walks whole bands of slab rows: when H == 1 (mod 14) its last one is the "extra" row, which only
+    // the last grid row may march (twice would write the same pixels again and count their samples twice)
+    if (gy != M.n_regular && P.conflict_y && by == P.nby - 1) return;
     {
         // ownership is decided on the pixel rows this slab row writes
         int yrow = (P.conflict_y && by == P.nby - 1) ? P.H - 2 : by * kSlab;
