@@ -46,7 +46,16 @@ def case(seed):
         cnt = int(rng.integers(2, 5)); shard = (int(rng.choice([4, 8])), cnt, int(rng.integers(0, cnt)))
     o = dict(step=step, filter=int(rng.choice([vv.FILTER_TEX8, vv.FILTER_EXACT])), ert_mode=int(rng.choice([vv.ERT_REFERENCE, vv.ERT_TRUE])),
              ert_threshold=float(rng.choice([0.01, 0.5, 0.95, 0.999, 1.5])), count_samples=bool(rng.random() < 0.7), shard=shard)
-    return vol, tf, W, H, cam, sp, bool(rng.random() < 0.45), o
+    phong = bool(rng.random() < 0.45)
+    # (second stream, added later: anisotropic steps -- pin 8 -- and slab-row ranges)
+    rng2 = np.random.default_rng(5000000 + seed)
+    if rng2.random() < 0.2:
+        o["step"] = tuple(float(v) for v in rng2.choice([1 / 5, 1 / 16, 1 / 40, 1 / 64], size=3))
+    if shard is None and rng2.random() < 0.2:
+        nby = H // 14 + (1 if H % 14 else 0)
+        a = int(rng2.integers(0, nby + 1)); b = int(rng2.integers(a, nby + 1))
+        o["slab_rows"] = (a, b)
+    return vol, tf, W, H, cam, sp, phong, o
 
 
 def main():
