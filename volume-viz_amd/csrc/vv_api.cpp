@@ -749,7 +749,9 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // Phong kernel: 14.3 KB of LDS per block + this reserve.  Measured (tools/ab_phong.sh): volumes up to
     // 1 GiB like 5 blocks per CU (C2 0.54 -> 0.47 ms against no cap, u8 1024^3 1.88 -> 1.78), the 4 GiB
     // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)
-    A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f) ? 30000 : 13000);
+    // (re-swept with the depth-limited refresh, tools/ab_phong_reserve.sh: C3 1.97 ms with 3, 4 or 5 blocks, 2.22 with 2; the
+    // bricked copy likes 5: rotated C3 + Phong 2.25 -> 2.13 ms; C5 5.95 ms with 2, 6.25 with 3, 6.55 with 5)
+    A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f && !use_bricks) ? 30000 : 13000);
     if (K.lds_reserve_phong >= 0 && K.lds_reserve_phong <= 146 * 1024) A.lds_reserve_phong = K.lds_reserve_phong;
     // Two x-adjacent slabs per block (waves of 32 x 2 threads across both; VV_PHONG_SPB=2): with the depth-limited
     // refresh it wins 2 % on C3 + Phong and loses 1-25 % on everything else (tools/ab_phong_cases.sh): opt-in.
