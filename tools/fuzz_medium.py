@@ -1,6 +1,7 @@
 """developer tool (1 GPU): parity fuzzing at sizes where vv_render's own policy picks the layout (bricked copy from 2 M
 voxels, z-pair copy, re-pitched rows for widths that are multiples of 256 voxels, several strips / slabs per XCD): no knob
-is forced.  usage: python3 tools/fuzz_medium.py <first seed> <last seed + 1>"""
+is forced -- unless FUZZ_KNOBS=1, which cycles the layout / launch-form knobs of tools/fuzz_wild.py over the same cases.
+usage: python3 tools/fuzz_medium.py <first seed> <last seed + 1>"""
 import os, sys
 import numpy as np
 REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -41,8 +42,16 @@ def main():
     ctx = vv.Context(0)
     bad = 0
     used = {"bricks": 0, "zpair": 0}
+    knobs = os.environ.get("FUZZ_KNOBS") == "1"
+    KNOBS = ("VV_BRICKED", "VV_ZPAIR", "VV_FORCE_BIG", "VV_PITCH_FORCE", "VV_SWEEP", "VV_WSTAGED", "VV_PHONG_SPB", "VV_PHONG_COMPACT")
+    ENVS = [{"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_FORCE_BIG": "1"}, {"VV_PITCH_FORCE": "1"}, {"VV_SWEEP": "1"}, {"VV_WSTAGED": "1"},
+            {"VV_PHONG_SPB": "2"}, {"VV_PHONG_COMPACT": "1"}, {"VV_BRICKED": "0"}, {"VV_FORCE_BIG": "1", "VV_BRICKED": "1"}]
     for seed in range(lo, hi):
         vol, tf, W, H, cam, sp, phong, o = case(seed)
+        if knobs:
+            for k in KNOBS:
+                os.environ.pop(k, None)
+            os.environ.update(ENVS[seed % len(ENVS)])
         ctx.load_volume(vol, tf)
         opts = vv.make_options(**o)
         got = ctx.render(W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
