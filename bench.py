@@ -338,8 +338,12 @@ def main():
         for name, camera, phong, what, tkey in (
                 ("rotated_view", cam_b, False, "camera on the orbit r=4, theta=60 deg, phi=36 deg: march_kernel on the bricked copy", "c3-noise-ramp-b-n1"),
                 ("phong", cam, True, "view a with central-difference gradient + Phong: march_phong_kernel", "c3-noise-ramp-a-phong-n1")):
-            ns_x, by_x = instrumented(camera, phong)
-            ms_x = timed(camera, phong)
+            try:
+                ns_x, by_x = instrumented(camera, phong)
+                ms_x = timed(camera, phong)
+            except Exception as e:          # a diagnostic beside the metric: never at the cost of the metric line
+                out[name] = {"what": what, "error": f"{type(e).__name__}: {e}"}
+                continue
             tr_x, note_x = measured_traffic(tkey)
             out[name] = {"what": what, "ms_per_frame": round(ms_x, 4), "value": round(ns_x / ms_x / 1e3, 1), "unit": "Msamples/s",
                          "executed_samples_per_frame": int(ns_x),
@@ -348,45 +352,51 @@ def main():
             if note_x:
                 out[name]["roofline"]["traffic_note"] = note_x
 
-    if want_cpu:
-        # The CPU restatement (oracle/vvo.c, OpenMP) on this box's host cores (the GPU box shares its host: 16 cores is
-        # the share of one GPU).  BASELINE.md section 3 asks for config C1: 128^3 drawDefaultBrain volume (u8, as the
-        # reference stores it), 512x512, step 1/128, Head transfer function, camera (0,0,-4); 1 thread and all threads.
-        sys.path.insert(0, os.path.join(REPO, "tests"))
-        import oracle_lib as O
-        cores = int(os.environ.get("VV_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
-        c1_vol = O.draw_default_brain(128, 128, 128)
-        c1_tf = vv.transfer_preset(vv.TF_HEAD)
-        c1_cam = vv.Camera()
-        budget = max(2.0, args.cpu_seconds * 0.5)
-        t = time.perf_counter(); sN = 0; reps = 0
-        while reps == 0 or (time.perf_counter() - t < budget and reps < 4096):
-            sN += O.render(c1_vol, c1_tf, 512, 512, c1_cam, threads=cores)[1]; reps += 1
-        dt = time.perf_counter() - t
-        out["cpu_baseline"] = {"value": round(sN / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                               "ms_per_frame": round(dt / reps * 1e3, 2),
-                               "sample": f"config C1: {reps} x the whole 512x512 frame of the 128^3 drawDefaultBrain volume, Head TF, step 1/128 "
-                                         f"({sN} samples in {dt:.1f} s; oracle/vvo.c, OpenMP, {cores} threads)"}
-        t = time.perf_counter()
-        s1 = O.render(c1_vol, c1_tf, 512, 512, c1_cam, threads=1)[1]
-        d1 = time.perf_counter() - t
-        out["cpu_baseline_1thread"] = {"value": round(s1 / d1 / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
-                                       "ms_per_frame": round(d1 * 1e3, 1), "sample": f"config C1, one frame ({s1} samples in {d1:.1f} s)"}
-    if want_cpu and host_vol is not None:
-        # the same port on the bench workload itself (C3), a slab-row band sized to the remaining time
-        nby = (H + 13) // 14
-        mid = nby // 2
-        cbase = {k: v for k, v in base.items() if k != "shard"}
-        t = time.perf_counter()
-        O.render(host_vol, tf, W, H, cam, options=vv.make_options(slab_rows=(mid, mid + 1), **cbase), threads=cores)
-        dt1 = time.perf_counter() - t
-        rows = int(max(1, min(nby, budget / max(dt1, 1e-3))))
-        lo = max(0, min(nby - rows, mid - rows // 2))
-        t = time.perf_counter()
-        sN = O.render(host_vol, tf, W, H, cam, options=vv.make_options(slab_rows=(lo, lo + rows), **cbase), threads=cores)[1]
-        dt = time.perf_counter() - t
-        out["cpu_baseline_c3"] = {"value": round(sN / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                                  "sample": f"slab rows [{lo},{lo + rows}) of {nby} of the bench frame itself ({sN} samples in {dt:.1f} s)"}
+    def cpu_baselines():
+        if want_cpu:
+            # The CPU restatement (oracle/vvo.c, OpenMP) on this box's host cores (the GPU box shares its host: 16 cores is
+            # the share of one GPU).  BASELINE.md section 3 asks for config C1: 128^3 drawDefaultBrain volume (u8, as the
+            # reference stores it), 512x512, step 1/128, Head transfer function, camera (0,0,-4); 1 thread and all threads.
+            sys.path.insert(0, os.path.join(REPO, "tests"))
+            import oracle_lib as O
+            cores = int(os.environ.get("VV_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+            c1_vol = O.draw_default_brain(128, 128, 128)
+            c1_tf = vv.transfer_preset(vv.TF_HEAD)
+            c1_cam = vv.Camera()
+            budget = max(2.0, args.cpu_seconds * 0.5)
+            t = time.perf_counter(); sN = 0; reps = 0
+            while reps == 0 or (time.perf_counter() - t < budget and reps < 4096):
+                sN += O.render(c1_vol, c1_tf, 512, 512, c1_cam, threads=cores)[1]; reps += 1
+            dt = time.perf_counter() - t
+            out["cpu_baseline"] = {"value": round(sN / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                                   "ms_per_frame": round(dt / reps * 1e3, 2),
+                                   "sample": f"config C1: {reps} x the whole 512x512 frame of the 128^3 drawDefaultBrain volume, Head TF, step 1/128 "
+                                             f"({sN} samples in {dt:.1f} s; oracle/vvo.c, OpenMP, {cores} threads)"}
+            t = time.perf_counter()
+            s1 = O.render(c1_vol, c1_tf, 512, 512, c1_cam, threads=1)[1]
+            d1 = time.perf_counter() - t
+            out["cpu_baseline_1thread"] = {"value": round(s1 / d1 / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                           "ms_per_frame": round(d1 * 1e3, 1), "sample": f"config C1, one frame ({s1} samples in {d1:.1f} s)"}
+        if want_cpu and host_vol is not None:
+            # the same port on the bench workload itself (C3), a slab-row band sized to the remaining time
+            nby = (H + 13) // 14
+            mid = nby // 2
+            cbase = {k: v for k, v in base.items() if k != "shard"}
+            t = time.perf_counter()
+            O.render(host_vol, tf, W, H, cam, options=vv.make_options(slab_rows=(mid, mid + 1), **cbase), threads=cores)
+            dt1 = time.perf_counter() - t
+            rows = int(max(1, min(nby, budget / max(dt1, 1e-3))))
+            lo = max(0, min(nby - rows, mid - rows // 2))
+            t = time.perf_counter()
+            sN = O.render(host_vol, tf, W, H, cam, options=vv.make_options(slab_rows=(lo, lo + rows), **cbase), threads=cores)[1]
+            dt = time.perf_counter() - t
+            out["cpu_baseline_c3"] = {"value": round(sN / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                                      "sample": f"slab rows [{lo},{lo + rows}) of {nby} of the bench frame itself ({sN} samples in {dt:.1f} s)"}
+
+    try:
+        cpu_baselines()
+    except Exception as e:          # the baseline is a report beside the metric: it must never cost the metric line
+        out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": f"not taken: {type(e).__name__}: {e}"}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
