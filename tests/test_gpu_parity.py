@@ -555,6 +555,32 @@ def test_wild_fuzz_subset(ctx, first, monkeypatch):
         assert n_got is None or n_got == n, what
 
 
+def test_sweep_tile_wider_than_the_frame(ctx, monkeypatch):
+    """A frame narrower than a sweep tile (96 x 8 pixels): the tile's frustum must be taken over the pixels that exist.
+    Beyond the frame's edge the rays' slope against the sweep axis can change sign (a thin, strongly scaled cube seen
+    from the side), and the slopes of the four tile corners then bound nothing: the footprints missed the volume and
+    the uninstrumented build rendered wrong pixels without a word (found by tools/fuzz_wild.py, seed 78805)."""
+    monkeypatch.setenv("VV_SWEEP", "1")
+    rng = np.random.default_rng(5)
+    vol = rng.random((31, 5, 4), dtype=np.float32)
+    tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
+    for origin, scale, W, H in (((-1.4479461520329102, 0.0, 1.3796564575332109), (0.1, 0.5, 0.5), 52, 54),
+                                ((1.2, 0.3, 1.6), (0.1, 0.5, 0.5), 40, 70), ((-0.9, 0.2, -2.2), (0.2, 1.0, 0.5), 30, 30)):
+        cam = vv.Camera(origin=origin, scale=scale)
+        o = dict(step=1 / 64, filter=vv.FILTER_EXACT, ert_threshold=1.5)
+        ctx.load_volume(vol, tf)
+        got = ctx.render(W, H, cam, options=vv.make_options(count_samples=True, **o), fill=0x3C)
+        n_got = ctx.last_sample_count()
+        cnt = ctx.debug_counters()
+        want, n = O.render(vol, tf, W, H, cam, options=vv.make_options(**o), fill=0x3C)
+        what = f"eye {origin} scale {scale} {W}x{H}"
+        assert cnt[4] == 0 and cnt[7] == 0, f"{what}: {cnt[4]} samples outside the LDS images, error flags {cnt[7]:#x}"
+        assert_frames_close(got, want, what)
+        assert n_got == n, what
+        got2 = ctx.render(W, H, cam, options=vv.make_options(**o), fill=0x3C)
+        assert np.array_equal(got2, want), what + " (uninstrumented)"
+
+
 def _sweep_case(rng):
     n = 4 * int(rng.integers(3, 18))
     dims = (n, n, n) if rng.random() < 0.5 else (4 * int(rng.integers(3, 18)), int(rng.integers(12, 72)), int(rng.integers(12, 72)))

@@ -274,6 +274,7 @@ int vv_debug_plan_sweep(int W, int H, const camera_params *cam, const vv_ray_sou
     A.V.row_bytes = (uint32_t)nx * vsz; A.V.slice_bytes = A.V.row_bytes * (uint32_t)ny;
     A.V_type = voxel_type; A.phong = phong != 0;
     A.sweep.nl = A.sweep.wx = A.sweep.wy = A.sweep.group = A.sweep.depth = A.sweep.lead = -1;
+    A.sweep.verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
     const int last_written = H >= 2 ? H - 2 : 0;
     plan_sweep(A, 0, ((last_written + 1 + 7) / 8) * 8, 0);
     const SweepArgs &S = A.sweep;

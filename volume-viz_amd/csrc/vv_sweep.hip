@@ -184,7 +184,9 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         const int lw = wave - S.nc;
         // frustum of the tile from its four corner pixels (pixel centres, ray_endpoints())
         Frustum F;
-        tile_frustum<MAJOR>(P, V, x0, y0, x0 + tile_w - 1, y0 + tile_h - 1, F);
+        // the rectangle of the tile's pixels that exist: slopes are ratios of affine functions of the pixel, monotone only
+        // where the denominator keeps its sign, which sweep_axis() checked for the frame's pixels and no further
+        tile_frustum<MAJOR>(P, V, min(x0, P.W - 1), min(y0, P.H - 1), min(x0 + tile_w - 1, P.W - 1), min(y0 + tile_h - 1, P.H - 1), F);
         FootLin FL;
         foot_linear(F, S.sgn > 0, FL);
         // one LDS-DMA piece = one row of the slice's image: lane l copies bytes [16 l, 16 l + 16) of the row
@@ -724,7 +726,7 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
             for (int tc = 0; tc < S.ntx; ++tc) {
                 double mxl = INFINITY, mxh = -INFINITY, mrl = INFINITY, mrh = -INFINITY;
                 for (int c = 0; c < 4; ++c) {
-                    double D[3]; dirD(tc * tw + ((c & 1) ? tw - 1 : 0), py0 + ((c & 2) ? th - 1 : 0), D);
+                    double D[3]; dirD(std::min(tc * tw + ((c & 1) ? tw - 1 : 0), P.W - 1), std::min(py0 + ((c & 2) ? th - 1 : 0), P.H - 1), D);   // as the kernel: pixels of the frame only
                     const double mx = D[xa] / D[sa], mr = D[ra] / D[sa];
                     mxl = std::min(mxl, mx); mxh = std::max(mxh, mx); mrl = std::min(mrl, mr); mrh = std::max(mrh, mr);
                 }
@@ -739,11 +741,13 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
                     hx_lo = std::min(hx_lo, E[xa] + xl); hx_hi = std::max(hx_hi, E[xa] + xh);
                     hr_lo = std::min(hr_lo, E[ra] + rl); hr_hi = std::max(hr_hi, E[ra] + rh);
                 }
+                if (verbose && getenv("VV_SWEEP_VERBOSE2")) fprintf(stderr, "  tile (%d,%d): x [%.2f, %.2f] rows [%.2f, %.2f] slopes x [%.3f, %.3f] r [%.3f, %.3f] ex %.2f er %.2f\n", tc, t, hx_lo, hx_hi, hr_lo, hr_hi, mxl, mxh, mrl, mrh, ex, er);
                 if (hx_hi < -2.0 || hx_lo > n[xa] + 1.0 || hr_hi < -2.0 || hr_lo > n[ra] + 1.0) continue;   // the tile's frustum misses the volume
                 ext_x = std::max(ext_x, ex); ext_r = std::max(ext_r, er);
             }
         }
         const double slack = 2.0 * kMargin + 0.01;
+        if (verbose) fprintf(stderr, "sweep: tile %dx%d waves: largest extent %.2f voxels in x, %.2f rows\n", S.wx, S.wy, ext_x, ext_r);
         S.pxc = (int)floor((ext_x + slack + 2.0) / 32.0) + 2;
         S.ry = (int)floor(ext_r + slack) + 3;
         S.pxc = std::min(S.pxc, (V.nx + 31) / 32 + 1);
