@@ -85,6 +85,8 @@ def main():
                 print("MISMATCH seed", seed, what, flush=True)
         if bad > 10:
             break
+        if seed % 500 == 0:
+            print("seed", seed, "mismatches so far", bad, flush=True)
     print(f"seeds {lo}..{hi - 1}: {bad} mismatches")
     sys.exit(1 if bad else 0)
 
