@@ -172,6 +172,13 @@ int  vv_set_transfer_function(vv_context *ctx, const float tf[1024]);
 int  vv_load_volume_stream_begin(vv_context *ctx, int voxel_type, int nx, int ny, int nz,
                                  const float tf[1024]);
 int  vv_load_volume_stream_slices(vv_context *ctx, const void *src, int src_type, int z0, int nslices);
+/* The same in two halves, for a host that feeds several contexts from one pinned buffer (volviz_mgpu) or wants to
+ * overlap its own work with the transfer: _async only enqueues (H2D copy, then the promotion kernel on a second
+ * stream), _wait_source returns when the copy engine has read every pinned source handed over so far -- the buffer may
+ * then be refilled; promotion kernels may still be running (stream_end waits for them).
+ * vv_load_volume_stream_slices == _async followed by _wait_source. */
+int  vv_load_volume_stream_slices_async(vv_context *ctx, const void *src, int src_type, int z0, int nslices);
+int  vv_load_volume_stream_wait_source(vv_context *ctx);
 int  vv_load_volume_stream_end(vv_context *ctx);
 /* .t3d file -> device volume in chunks (never holds the file in memory); voxel_type F32 promotes. */
 int  vv_load_volume_t3d(vv_context *ctx, const char *path, int header, int voxel_type,

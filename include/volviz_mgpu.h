@@ -5,8 +5,9 @@
  * north_star adds: the frame is cut into bands of 4 slab rows (56 pixel rows) dealt round-robin to the
  * devices (vv_render_options.shard_*), the volume is replicated, nothing is exchanged during the march,
  * and the bands are gathered once per frame over xGMI into the frame on device 0:
- * ncclCommInitAll + one ncclGroupStart { ncclSend per band on its device, ncclRecv per band on device 0,
- * straight into the band's rows of the destination frame } ncclGroupEnd  (rccl.h:236,700,722).
+ * ncclCommInitAll + one ncclGroupStart { ncclSend per band on its device, ncclRecv per band on device 0 into a
+ * landing frame } ncclGroupEnd  (rccl.h:236,700,722), then the written (W-1)-pixel part of each received row is copied
+ * into the destination frame, so the pixels the reference never writes keep the caller's bytes.
  * bench.py's torchrun path (one process per GPU, torch.distributed gather) is the same design for Python hosts.
  */
 #ifndef VOLVIZ_MGPU_H
@@ -30,7 +31,8 @@ int  vv_mgpu_load_volume_f32(vv_mgpu *m, const float *texels, size_t size, int n
 /* The volume generated on every device (no host copy, no PCIe): drawDefaultBrain at nx x ny x nz, as u8 or promoted to f32. */
 int  vv_mgpu_generate_default_brain(vv_mgpu *m, int voxel_type, int nx, int ny, int nz, const float tf[1024]);
 /* C5: each device streams the u8 volume slab by slab from the caller's (pinned) host memory through
- * vv_load_volume_stream_* -- promoted to f32 on the device when voxel_type is VV_VOXEL_F32. */
+ * vv_load_volume_stream_* -- promoted to f32 on the device when voxel_type is VV_VOXEL_F32.  A slab is enqueued on every
+ * device before any is waited for (each device has its own PCIe link); promotion overlaps the next slab's copies. */
 int  vv_mgpu_stream_volume_u8(vv_mgpu *m, const uint8_t *texels, int voxel_type, int nx, int ny, int nz,
                               int slices_per_call, const float tf[1024]);
 
@@ -41,6 +43,12 @@ int  vv_mgpu_render(vv_mgpu *m, int width, int height, const struct slice_params
                     const struct camera_params *camera, const struct shading_params *shading,
                     const vv_ray_source *rays, const vv_render_options *opts,
                     uint8_t *rgba_out, int out_on_device);
+/* The gather's bookkeeping (host arithmetic, no device): band b of a frame of height H rendered on n devices belongs to
+ * *rank = b % n; of its 56 pixel rows that rank writes [*y_begin, *y_end) -- clipped to the slab-row range of the options
+ * (0, 0 = all) and to row H-2, since row H-1 is never written (kernel.cu:297-298).  vv_mgpu_render sends exactly these
+ * rows and copies columns 0 .. W-2 of them into the destination. */
+int  vv_mgpu_band_rows(int height, int n_devices, int slab_row_begin, int slab_row_end, int band,
+                       int *rank, int *y_begin, int *y_end);
 /* per-rank march time of the last frame in ms (hipEvent), and the gather's */
 int  vv_mgpu_last_times(vv_mgpu *m, float *march_ms /* [n] */, float *gather_ms);
 const char *vv_mgpu_last_error(const vv_mgpu *m);

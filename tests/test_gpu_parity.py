@@ -405,31 +405,6 @@ def test_render_interleaved_shards(ctx, W, H):
             assert_frames_close(got, want)
 
 
-@pytest.mark.parametrize("view", ["a", "b", "c"])
-def test_staged_kernel_is_bit_identical(ctx, view, monkeypatch):
-    """The opt-in wave-private LDS brick cache march (VV_WSTAGED=1) must produce the same frames
-    and sample counts as the oracle: u8 and f32, every slice mode, ragged volume sizes, ERT modes."""
-    monkeypatch.setenv("VV_WSTAGED", "1")
-    tf = vv.transfer_preset(vv.TF_ENGINE)
-    cam = _cam(view)
-    for dims, dtype, st in (((64, 64, 64), np.uint8, vv.SLICE_NONE), ((48, 40, 36), np.float32, vv.SLICE_PLANE),
-                            ((32, 64, 16), np.uint8, vv.SLICE_PLANE_CUT), ((16, 16, 200), np.float32, vv.SLICE_NONE)):
-        vol = O.noise_u8(*dims, 7) if st == vv.SLICE_NONE else O.draw_default_brain(*dims)
-        if dtype == np.float32:
-            vol = vol.astype(np.float32) / np.float32(255)
-        ctx.load_volume(vol, tf)
-        sp = vv.make_slice_params(st, PLANE_POINT, PLANE_NORMAL)
-        for ert in (vv.ERT_REFERENCE, vv.ERT_TRUE):
-            opts = vv.make_options(count_samples=True, ert_mode=ert, ert_threshold=0.9)
-            got = ctx.render(150, 97, cam, slice=sp, options=opts, fill=0x11)
-            n_got = ctx.last_sample_count()
-            want, n = O.render(vol, tf, 150, 97, cam, slice=sp, options=opts, fill=0x11)
-            assert_frames_close(got, want, f"staged {dims} {np.dtype(dtype).name} s{st} ert{ert}")
-            assert n_got == n
-    # the staged path really ran (it reports its stages)
-    assert ctx.debug_counters()[1] > 0
-
-
 SWEEP_CAMS = {
     "z+": vv.Camera(),                                                             # along +z (the headline view)
     "z-": vv.Camera(origin=(0.3, 0.2, 4.0)),                                       # along -z
@@ -496,8 +471,8 @@ def test_tables_with_opacity_outside_unit_interval(ctx, phong, monkeypatch):
     for k, (lo, hi) in enumerate(((0.0, 2.5), (-0.5, 1.8), (0.0, 1.0))):
         tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
         tf[:, 3] = rng.uniform(lo, hi, 256).astype(np.float32)
-        for env in ({}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_SWEEP": "1"}, {"VV_WSTAGED": "1"}):
-            for name in ("VV_BRICKED", "VV_ZPAIR", "VV_SWEEP", "VV_WSTAGED"):
+        for env in ({}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_SWEEP": "1"}, {"VV_SKEW": "3"}, {"VV_SKEW": "1", "VV_UNROLL": "1"}):
+            for name in ("VV_BRICKED", "VV_ZPAIR", "VV_SWEEP", "VV_SKEW", "VV_UNROLL"):
                 monkeypatch.delenv(name, raising=False)
             for name, val in env.items():
                 monkeypatch.setenv(name, val)
@@ -636,14 +611,9 @@ def test_sweep_kernel_seeded(ctx, seed, monkeypatch):
     assert np.array_equal(got2, want), what + " (uninstrumented)"
 
 
-@pytest.mark.parametrize("spb,compact", [(1, 0), (2, 0), (1, 1), (2, 1)])
-def test_phong_blocks_of_several_slabs_are_bit_identical(ctx, spb, compact, monkeypatch):
-    """march_phong_kernel's launch forms (speed only): one or two x-adjacent slabs per block (each slab keeps its own
-    apron, radius and sample cache), and the cache refresh either by every thread for its own ray or dealt out as
-    (needed ray, quarter) work items.  The sweep's cases with Phong forced on, frame widths that leave ghost slabs at
-    the row's end, W == 1 (mod 14), shards, every layout, instrumented and not -- same frames, same sample counts."""
-    monkeypatch.setenv("VV_PHONG_SPB", str(spb))
-    monkeypatch.setenv("VV_PHONG_COMPACT", str(compact))
+def test_phong_forced_on_the_random_cases(ctx):
+    """march_phong_kernel on the sweep's cases with Phong forced on, frame widths with W == 1 (mod 14), shards, instrumented
+    and not -- same frames, same sample counts."""
     for seed in range(0, 48, 5):
         vol, tf, W, H, cam, sp, _, o = _random_case(seed)
         ctx.load_volume(vol, tf)
@@ -651,11 +621,11 @@ def test_phong_blocks_of_several_slabs_are_bit_identical(ctx, spb, compact, monk
         got = ctx.render(W, H, cam, slice=sp, phong=True, options=opts, fill=0x3C)
         n_got = ctx.last_sample_count()
         want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=True, options=opts, fill=0x3C)
-        assert_frames_close(got, want, f"phong spb={spb} seed {seed}: {vol.shape} {vol.dtype} {W}x{H}")
+        assert_frames_close(got, want, f"phong seed {seed}: {vol.shape} {vol.dtype} {W}x{H}")
         assert n_got == n
         o2 = dict(o); o2["count_samples"] = False
         got2 = ctx.render(W, H, cam, slice=sp, phong=True, options=vv.make_options(**o2), fill=0x3C)      # the uninstrumented build
-        assert np.array_equal(got2, got), f"phong spb={spb} compact={compact} seed {seed} (uninstrumented)"
+        assert np.array_equal(got2, got), f"phong seed {seed} (uninstrumented)"
     vol = O.draw_default_brain(64, 64, 64)
     tf = vv.transfer_preset(vv.TF_ENGINE)
     ctx.load_volume(vol, tf)
@@ -665,8 +635,53 @@ def test_phong_blocks_of_several_slabs_are_bit_identical(ctx, spb, compact, monk
             got = ctx.render(W, H, cam, phong=True, options=o, fill=7)
             n_got = ctx.last_sample_count()
             want, n = O.render(vol, tf, W, H, cam, phong=True, options=o, fill=7)
-            assert_frames_close(got, want, f"phong spb={spb} {W}x{H} shard={shard}")
+            assert_frames_close(got, want, f"phong {W}x{H} shard={shard}")
             assert n_got == n
+
+
+SKEW_ENVS = [{"VV_SKEW": "3"}, {"VV_SKEW": "1", "VV_UNROLL": "1"}, {"VV_SKEW": "2", "VV_UNROLL": "2"}, {"VV_SKEW": "3", "VV_FORCE_BIG": "1"},
+             {"VV_SKEW": "3", "VV_ZPAIR": "1"}, {"VV_SKEW": "2", "VV_BRICKED": "1"}]
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_skewed_lock_step_is_bit_identical(ctx, seed, monkeypatch):
+    """march_skew_kernel (lanes of a wave offset in sample index so that they sit on the same slices; VV_SKEW forces it and
+    its axis): the sweep's unshaded cases -- cutting planes, both ERT modes, scaled cubes, tables with any opacity -- on every
+    layout and with 1, 2 and 3 samples per trip, instrumented and not: same frames, same sample counts as the oracle."""
+    for k, v in SKEW_ENVS[seed % len(SKEW_ENVS)].items():
+        monkeypatch.setenv(k, v)
+    vol, tf, W, H, cam, sp, _, o = _random_case(seed)
+    ctx.load_volume(vol, tf)
+    opts = vv.make_options(**o)
+    got = ctx.render(W, H, cam, slice=sp, options=opts, fill=0x3C)
+    n_got = ctx.last_sample_count()
+    want, n = O.render(vol, tf, W, H, cam, slice=sp, options=opts, fill=0x3C)
+    what = f"skew seed {seed} {SKEW_ENVS[seed % len(SKEW_ENVS)]}: {vol.shape} {vol.dtype} {W}x{H} {o}"
+    assert_frames_close(got, want, what)
+    assert n_got == n, what
+    o2 = dict(o); o2["count_samples"] = False
+    got2 = ctx.render(W, H, cam, slice=sp, options=vv.make_options(**o2), fill=0x3C)
+    assert np.array_equal(got2, want), what + " (uninstrumented)"
+
+
+def test_skewed_lock_step_larger_frames(ctx, monkeypatch):
+    """The same on frames where a wave's lanes really differ in depth (wide fields of view close to the cube, long rays)."""
+    monkeypatch.setenv("VV_SKEW", "3")
+    vol = O.noise_u8(96, 80, 112, 5).astype(np.float32) / np.float32(255)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    for cam, W, H, step in ((vv.Camera(), 320, 200, 1 / 200), (vv.Camera.orbit(2.2, 1.2, -1.3), 257, 131, 1 / 150),
+                            (vv.Camera.orbit(1.9, 0.3, 0.4, scale=(0.8, 1.0, 1.57)), 200, 160, 1 / 90)):
+        for ert in (vv.ERT_REFERENCE, vv.ERT_TRUE):
+            for st in (vv.SLICE_NONE, vv.SLICE_PLANE, vv.SLICE_PLANE_CUT):
+                sp = vv.make_slice_params(st, (0.45, 0.5, 0.55), (0.3, -0.2, 1.0))
+                o = dict(step=step, ert_mode=ert, ert_threshold=0.9, count_samples=True)
+                got = ctx.render(W, H, cam, slice=sp, options=vv.make_options(**o), fill=0x11)
+                n_got = ctx.last_sample_count()
+                want, n = O.render(vol, tf, W, H, cam, slice=sp, options=vv.make_options(**o), fill=0x11)
+                what = f"skew {W}x{H} step {step:.4f} ert{ert} slice{st}"
+                assert_frames_close(got, want, what)
+                assert n_got == n, what
 
 
 @pytest.mark.parametrize("seed", range(0, 48, 3))

@@ -21,19 +21,18 @@ using namespace vv;
 // volume load -- never on the per-frame path.
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
-    int bricked = -1, zpair = -1, wstaged = 0, sweep = -1, sweep_trace = 0, force_big = 0;
-    int phong_spb = -1, phong_compact = -1;
-    int sw_nl = -1, sw_wx = -1, sw_wy = -1, sw_group = -1, sw_depth = -1, sw_lead = -1, sw_verbose = 0;
+    int bricked = -1, zpair = -1, sweep = -1, sweep_trace = 0, force_big = 0;
+    int skew = -1;
+    int sw_nl = -1, sw_wx = -1, sw_wy = -1, sw_group = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
     {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
-        bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1); wstaged = geti("VV_WSTAGED", 0);
-        phong_spb = geti("VV_PHONG_SPB", -1);
-        phong_compact = geti("VV_PHONG_COMPACT", -1);
+        bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
+        skew = geti("VV_SKEW", -1);
         sw_nl = geti("VV_SWEEP_NL", -1); sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_group = geti("VV_SWEEP_GROUP", -1);
-        sw_depth = geti("VV_SWEEP_DEPTH", -1); sw_lead = geti("VV_SWEEP_LEAD", -1); sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
+        sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
     }
 };
@@ -64,8 +63,9 @@ struct vv_context {
     unsigned long long *d_trace = nullptr; int trace_blocks = 0;      // developer trace of the sweep kernel (VV_SWEEP_TRACE=1)
     bool counter_valid = false;
     // streamed upload
-    hipStream_t copy_stream = nullptr;
-    void *pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2] = {nullptr, nullptr}; int pin_next = 0;
+    hipStream_t copy_stream = nullptr, promo_stream = nullptr;   // H2D copies / u8 -> f32 promotion kernels
+    void *pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2] = {nullptr, nullptr}; int pin_next = 0;   // pin_ev[b]: staging buffers b free again
+    hipEvent_t src_ev[2] = {nullptr, nullptr}; int src_last = -1;       // src_ev[b]: the copy engine has read piece b's source
     uint8_t *d_stage[2] = {nullptr, nullptr};     // u8 slices awaiting promotion
     bool streaming = false;
     std::string err;
@@ -159,9 +159,11 @@ int vv_shutdown(vv_context *c)
     for (int i = 0; i < 2; ++i) {
         if (c->pin[i]) hipHostFree(c->pin[i]);
         if (c->pin_ev[i]) hipEventDestroy(c->pin_ev[i]);
+        if (c->src_ev[i]) hipEventDestroy(c->src_ev[i]);
         if (c->d_stage[i]) hipFree(c->d_stage[i]);
     }
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    if (c->promo_stream) hipStreamDestroy(c->promo_stream);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -273,7 +275,7 @@ int vv_debug_plan_sweep(int W, int H, const camera_params *cam, const vv_ray_sou
     A.V.data = (const void *)(uintptr_t)256; A.V.nx = nx; A.V.ny = ny; A.V.nz = nz;
     A.V.row_bytes = (uint32_t)nx * vsz; A.V.slice_bytes = A.V.row_bytes * (uint32_t)ny;
     A.V_type = voxel_type; A.phong = phong != 0;
-    A.sweep.nl = A.sweep.wx = A.sweep.wy = A.sweep.group = A.sweep.depth = A.sweep.lead = -1;
+    A.sweep.nl = A.sweep.wx = A.sweep.wy = A.sweep.group = -1;
     A.sweep.verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
     const int last_written = H >= 2 ? H - 2 : 0;
     plan_sweep(A, 0, ((last_written + 1 + 7) / 8) * 8, 0);
@@ -336,7 +338,9 @@ int vv_load_volume_stream_begin(vv_context *c, int vtype, int nx, int ny, int nz
     if (c->d_vol) { HIPCHK(c, hipFree(c->d_vol)); c->d_vol = nullptr; }
     HIPCHK(c, hipMalloc(&c->d_vol, bytes + pad));
     if (!c->copy_stream) HIPCHK(c, hipStreamCreate(&c->copy_stream));
+    if (!c->promo_stream) HIPCHK(c, hipStreamCreate(&c->promo_stream));
     HIPCHK(c, hipMemsetAsync((char *)c->d_vol + bytes, 0, pad, c->copy_stream));
+    c->src_last = -1;
     c->vol_bytes = bytes; c->vtype = vtype; c->nx = nx; c->ny = ny; c->nz = nz;
     c->row_pitch = (size_t)nx * vsz; c->slice_pitch = c->row_pitch * ny; c->alloc_bytes = bytes + pad;
     c->streaming = true;
@@ -344,7 +348,11 @@ int vv_load_volume_stream_begin(vv_context *c, int vtype, int nx, int ny, int nz
     return VV_OK;
 }
 
-int vv_load_volume_stream_slices(vv_context *c, const void *src, int src_type, int z0, int nslices)
+// Enqueue only.  H2D copies run on copy_stream, promotion kernels on promo_stream behind the copy's event, so the copy of
+// the next piece overlaps the promotion of this one.  Two events per staging slot: src_ev (the copy engine has read the
+// source: what a caller that refills a pinned buffer has to wait for) and pin_ev (copy AND promotion done: the slot's
+// staging buffers may be reused).
+int vv_load_volume_stream_slices_async(vv_context *c, const void *src, int src_type, int z0, int nslices)
 {
     if (!c || !c->streaming) return fail(c, VV_ERR_INVALID, "stream_slices: no stream_begin");
     if (!src || z0 < 0 || nslices < 1 || z0 + nslices > c->nz) return fail(c, VV_ERR_INVALID, "stream_slices: bad slice range");
@@ -364,7 +372,8 @@ int vv_load_volume_stream_slices(vv_context *c, const void *src, int src_type, i
         const size_t nv = std::min(piece_vox_max, total_vox - done);
         const int b = c->pin_next; c->pin_next ^= 1;
         if (!c->pin_ev[b]) HIPCHK(c, hipEventCreate(&c->pin_ev[b]));
-        HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));          // buffer b free again
+        if (!c->src_ev[b]) HIPCHK(c, hipEventCreate(&c->src_ev[b]));
+        HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));          // staging slot b free again
         const char *hsrc = (const char *)src + done * ssz;
         if (!pinned) {
             if (!c->pin[b]) HIPCHK(c, hipHostMalloc(&c->pin[b], kStageBytes, hipHostMallocDefault));
@@ -374,20 +383,43 @@ int vv_load_volume_stream_slices(vv_context *c, const void *src, int src_type, i
         char *dst = (char *)c->d_vol + ((size_t)z0 * slice_vox + done) * dsz;
         if (!promote) {
             HIPCHK(c, hipMemcpyAsync(dst, hsrc, nv * ssz, hipMemcpyHostToDevice, c->copy_stream));
+            HIPCHK(c, hipEventRecord(c->src_ev[b], c->copy_stream));
+            HIPCHK(c, hipEventRecord(c->pin_ev[b], c->copy_stream));
         } else {
             if (!c->d_stage[b]) HIPCHK(c, hipMalloc((void **)&c->d_stage[b], kStageBytes));
             HIPCHK(c, hipMemcpyAsync(c->d_stage[b], hsrc, nv, hipMemcpyHostToDevice, c->copy_stream));
-            launch_promote_u8_f32(c->d_stage[b], (float *)dst, nv, c->copy_stream);
+            HIPCHK(c, hipEventRecord(c->src_ev[b], c->copy_stream));
+            HIPCHK(c, hipStreamWaitEvent(c->promo_stream, c->src_ev[b], 0));
+            launch_promote_u8_f32(c->d_stage[b], (float *)dst, nv, c->promo_stream);
             HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(c->pin_ev[b], c->promo_stream));
         }
-        HIPCHK(c, hipEventRecord(c->pin_ev[b], c->copy_stream));
-        // A pinned source is read by the copy engine straight from the caller's buffer: do not return before that read is
-        // over, or a producer that refills the buffer would race it.  (Pageable sources were copied into our own staging
-        // buffer above; their transfer keeps overlapping the caller's next fill.)
-        if (pinned) HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));
+        c->src_last = pinned ? b : -1;             // (pageable sources were copied into our own staging buffer above)
         done += nv;
     }
     return VV_OK;
+}
+
+// Returns when the copy engine has read every pinned source buffer handed to ..._slices_async so far (copies are in
+// order on one stream: the last one's event covers the earlier ones).  Does not wait for promotion kernels.
+int vv_load_volume_stream_wait_source(vv_context *c)
+{
+    if (!c) return fail(nullptr, VV_ERR_INVALID, "stream_wait_source: NULL context");
+    if (c->src_last < 0) return VV_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->src_ev[c->src_last]));
+    c->src_last = -1;
+    return VV_OK;
+}
+
+// A pinned source is read by the copy engine straight from the caller's buffer: do not return before that read is over, or
+// a producer that refills the buffer would race it.  (The transfer of a pageable source keeps overlapping the caller's
+// next fill; the promotion of a pinned piece overlaps it too.)
+int vv_load_volume_stream_slices(vv_context *c, const void *src, int src_type, int z0, int nslices)
+{
+    int rc = vv_load_volume_stream_slices_async(c, src, src_type, z0, nslices);
+    if (rc) return rc;
+    return vv_load_volume_stream_wait_source(c);
 }
 
 int vv_load_volume_stream_end(vv_context *c)
@@ -395,7 +427,8 @@ int vv_load_volume_stream_end(vv_context *c)
     if (!c || !c->streaming) return fail(c, VV_ERR_INVALID, "stream_end: no stream_begin");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
-    c->streaming = false;
+    HIPCHK(c, hipStreamSynchronize(c->promo_stream));
+    c->streaming = false; c->src_last = -1;
     { int rc = finalize_layout(c, c->copy_stream); if (rc) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     return VV_OK;
@@ -718,7 +751,15 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     A.unroll = (A.strips.tile_log2w == 5 || beyond_caches) ? 3 : 2;
     // (re-swept with tools/ab_reserve.sh at the end of round 1: 4 blocks per CU for volumes up to 1 GiB)
     A.lds_reserve = !beyond_caches ? 36000 : (A.strips.tile_log2w == 5 ? big_reserve : 155000);
-    const bool k_unroll = K.unroll == 2 || K.unroll == 3, k_reserve = K.lds_reserve >= 0 && K.lds_reserve <= 155 * 1024;
+    // Skewed lock step (march_skew_kernel, speed only): lanes of a wave aligned along the axis the rays march along (y or
+    // z, whichever the central ray crosses more steeply in voxels per sample).  VV_SKEW=0/1/2 overrides (1 / 2: the axis).
+    A.strips.skew_axis = 0;
+    if (rays->mode == VV_RAYS_ANALYTIC && !shading->phongShading) {
+        const float sy = fabsf(P.look[1] * P.step[1] * P.inv_scale[1] * (float)c->ny), sz = fabsf(P.look[2] * P.step[2] * P.inv_scale[2] * (float)c->nz);
+        const int ax = sz >= sy ? 2 : 1;
+        if (K.skew > 0) A.strips.skew_axis = K.skew <= 2 ? K.skew : ax;
+    }
+    const bool k_unroll = K.unroll >= 1 && K.unroll <= 3, k_reserve = K.lds_reserve >= 0 && K.lds_reserve <= 155 * 1024;
     if (k_unroll) A.unroll = K.unroll;
     if (k_reserve) A.lds_reserve = K.lds_reserve;
     // Bricked copy (speed only): off the memory axis the linear layout costs one cache line per lane
@@ -754,12 +795,6 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // bricked copy likes 5: rotated C3 + Phong 2.25 -> 2.13 ms; C5 5.95 ms with 2, 6.25 with 3, 6.55 with 5)
     A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f && !use_bricks) ? 30000 : 13000);
     if (K.lds_reserve_phong >= 0 && K.lds_reserve_phong <= 146 * 1024) A.lds_reserve_phong = K.lds_reserve_phong;
-    // Two x-adjacent slabs per block (waves of 32 x 2 threads across both; VV_PHONG_SPB=2): with the depth-limited
-    // refresh it wins 2 % on C3 + Phong and loses 1-25 % on everything else (tools/ab_phong_cases.sh): opt-in.
-    A.phong_spb = 1;
-    if (K.phong_spb == 1 || K.phong_spb == 2) A.phong_spb = K.phong_spb;
-    // Cache refresh dealt out as (needed ray, quarter) items: 5 % fewer gathers on C3 + Phong, 4-6 % slower (opt-in)
-    A.phong_compact = K.phong_compact == 1;
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
     int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));
@@ -789,29 +824,22 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         if (A.V.bricks) launch_raymarch_bricked(A, st); else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big) launch_raymarch_big(A, st); else launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
-        // Wave-private LDS brick cache (vv_raymarch_wstaged.hip): bit-identical to march_kernel
-        // but, as measured on MI355X in round 1, slower (C3 along z: 2.6 ms vs 1.6 ms; rotated
-        // view: 8.8 ms vs 6.8 ms), so it is opt-in (VV_WSTAGED=1) and kept as the base for the
-        // staged design of DESIGN.md section 4.  It needs 16-byte aligned rows and <= 4 GiB.
-        bool wst = false;
-        if (K.wstaged) wst = (A.V.row_bytes % 16u) == 0 && !A.V.big && c->tf_alpha_unit;
         // Slab sweep (vv_sweep.hip): the volume streamed through LDS by dedicated loader waves.
         bool sweep = false;
         if (K.sweep >= 0) sweep = K.sweep != 0;
-        if (sweep && !wst) {
+        if (sweep) {
             const int own_bands = s_count > 1 ? A.strips.n_strips / A.strips.strips_per_band : 0;
-            A.sweep.nl = K.sw_nl; A.sweep.wx = K.sw_wx; A.sweep.wy = K.sw_wy; A.sweep.group = K.sw_group; A.sweep.depth = K.sw_depth;
-            A.sweep.lead = K.sw_lead; A.sweep.verbose = K.sw_verbose;
+            A.sweep.nl = K.sw_nl; A.sweep.wx = K.sw_wx; A.sweep.wy = K.sw_wy; A.sweep.group = K.sw_group;
+            A.sweep.verbose = K.sw_verbose;
             plan_sweep(A, A.strips.y0, A.strips.n_strips * 8, own_bands);
             sweep = A.sweep.enabled != 0;
         }
-        if (sweep && !wst && K.sweep_trace) {
+        if (sweep && K.sweep_trace) {
             const int nb = ((A.sweep.nty + 7) / 8) * 8 * A.sweep.ntx;
             if (!c->d_trace) { if (hipMalloc((void **)&c->d_trace, 8ull * 8 * 65536) != hipSuccess) c->d_trace = nullptr; }
             if (c->d_trace && nb <= 65536) { HIPCHK(c, hipMemsetAsync(c->d_trace, 0, 64ull * nb, st)); A.sweep.trace = c->d_trace; c->trace_blocks = nb; }
         }
-        if (sweep && !wst) launch_raymarch_sweep(A, st);
-        else if (wst) launch_raymarch_wstaged(A, st);
+        if (sweep) launch_raymarch_sweep(A, st);
         else if (A.V.bricks) launch_raymarch_bricked(A, st);
         else if (A.V.zpair) launch_raymarch_zpair(A, st);
         else if (A.V.big) launch_raymarch_big(A, st);

@@ -290,10 +290,6 @@ __device__ __forceinline__ void load_rows(const char *b00, uint32_t row_bytes, u
     const char *b11 = b01 + row_bytes;
     if constexpr (VOXEL == VV_VOXEL_F32) {
         const uint32_t off = ix * 4u + yz;
-#ifdef VV_X_NOLOAD
-        // experiment build (tools/decompose.sh): keep the address arithmetic, drop the gathers
-        { float f = __uint_as_float((off & 0xffffu) | 0x3a000000u); C.a = {f, f}; C.b = C.a; C.c = C.a; C.d = C.a; return; }
-#endif
         C.a = *(const float2u *)(b00 + off); C.b = *(const float2u *)(b10 + off);
         C.c = *(const float2u *)(b01 + off); C.d = *(const float2u *)(b11 + off);
     } else {
@@ -349,12 +345,6 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
         if constexpr (VOXEL == VV_VOXEL_F32) {
             const uint32_t ox = __umul24(ix >> G::xlog2, G::brick) + ((ix & (G::bx - 1u)) << 2);
             const uint32_t o0 = ox + oy0, o1 = ox + oy1;
-#ifdef VV_X_NOLOAD
-            {   // experiment build (tools/decompose.sh): keep the address arithmetic, drop the gathers
-                const uint64_t h = (uint64_t)(L0 + (o0 + zi0)) ^ (uint64_t)(L0 + (o1 + zi0)) ^ (uint64_t)(L1 + (o0 + zi1)) ^ (uint64_t)(L1 + (o1 + zi1));
-                float f = __uint_as_float(((uint32_t)h & 0xffffu) | 0x3a000000u); C.a = {f, f}; C.b = C.a; C.c = C.a; C.d = C.a; return;
-            }
-#endif
             if constexpr (G::halo != 0) {
                 C.a = *(const float2u *)(L0 + (o0 + zi0)); C.b = *(const float2u *)(L0 + (o1 + zi0));
                 C.c = *(const float2u *)(L1 + (o0 + zi1)); C.d = *(const float2u *)(L1 + (o1 + zi1));

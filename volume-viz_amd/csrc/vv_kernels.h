@@ -6,7 +6,9 @@
 namespace vv {
 
 // blockIdx.y -> pixel strip (march_kernel) / slab row (march_phong_kernel) of a shard
-struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips, xcd_band; };
+struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips, xcd_band;
+                  int skew_axis; };   // 0: lock-step march_kernel; 1 / 2: march_skew_kernel, lanes aligned along y / z
+
 struct SlabMap  { int r0, band, band_stride, n_regular; };
 
 // Slab sweep (vv_sweep.hip): a block of nc = wx * wy consumer waves (32 x 2 pixels each) + `nl` loader waves owns a
@@ -21,8 +23,6 @@ struct SweepArgs {
     int ntx, nty;          // tile grid
     int y0, rows_per_band, band_stride_px;   // pixel row of tile row t: y0 + (t / rows_per_band) * band_stride_px + (t % rows_per_band) * 2 wy
     int group;             // slices per loader group (one footprint, one allocation, one confirmation)
-    int depth;             // groups a loader wave keeps pending
-    int lead;              // > 0: one more wave prefetches the slices `lead` beyond the ring into L2
     int pxc, ry, ring;     // LDS image of a slice: ry rows of pxc 128-byte cells; `ring` slots (power of two)
     int slot_bytes;        // pxc * 128 * ry
     int lds_bytes;         // dynamic LDS of the launch
@@ -37,10 +37,8 @@ struct MarchArgs {
     int V_type;                 // vv_voxel_type
     bool tex8, gray, phong, instr;
     int lds_reserve;            // march_kernel: dynamic LDS bytes reserved only to cap blocks per CU
-    int unroll;                 // march_kernel: samples per loop trip (2 or 3)
-    int lds_reserve_phong;      // march_phong_kernel: same occupancy cap (its own LDS is 5 KB + 9 KB per slab)
-    int phong_spb;              // march_phong_kernel: x-adjacent slabs per block (1 or 2)
-    int phong_compact;          // march_phong_kernel: refresh only the cache entries a compositing ray reads
+    int unroll;                 // march_kernel: samples per loop trip (2 or 3; march_skew_kernel also 1)
+    int lds_reserve_phong;      // march_phong_kernel: same occupancy cap (its own LDS is 14 KB)
     SweepArgs sweep;                   // sweep_kernel (vv_sweep.hip)
     StripMap strips;                   // march_kernel: strips of 8 pixel rows (n_strips of them)
     SlabMap slabs;                     // march_phong_kernel grid.y = n_regular + 1
@@ -63,7 +61,6 @@ void launch_repitch(const void *dense, void *pitched, size_t row_bytes /* multip
                     size_t row_pitch, size_t slice_pitch, hipStream_t s);
 size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_t *sz64);
 void launch_build_bricks(int vtype, const void *linear, size_t row_pitch, size_t slice_pitch, void *bricks, int nx, int ny, int nz, hipStream_t s);
-void launch_raymarch_wstaged(const MarchArgs &a, hipStream_t s);  // wave-private LDS brick cache (no Phong)
 void launch_raymarch_sweep(const MarchArgs &a, hipStream_t s);    // block-wide slab sweep, LDS slice ring filled by LDS-DMA (f32, no Phong)
 // host-side sizing of the sweep for a frame (fills a.sweep; enabled = 0 if the frame does not qualify)
 void plan_sweep(MarchArgs &a, int first_tile_row_px, int n_pixel_rows, int own_bands);

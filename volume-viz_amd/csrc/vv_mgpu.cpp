@@ -20,6 +20,7 @@ struct vv_mgpu {
     std::vector<hipEvent_t> e0, e1;
     hipEvent_t g0 = nullptr, g1 = nullptr;
     std::vector<uint8_t *> frame; std::vector<size_t> frame_cap;     // per-device full-size frames (device 0: staging for host output)
+    uint8_t *land = nullptr; size_t land_cap = 0;                    // device 0: where the other ranks' bands are received
     std::string err;
 };
 
@@ -83,6 +84,7 @@ int vv_mgpu_shutdown(vv_mgpu *m)
         if (r < (int)m->stream.size() && m->stream[r]) (void)hipStreamDestroy(m->stream[r]);
         if (r < (int)m->ctx.size() && m->ctx[r]) (void)vv_shutdown(m->ctx[r]);
     }
+    if (m->land) { (void)hipSetDevice(m->dev[0]); (void)hipFree(m->land); }
     if (m->g0) (void)hipEventDestroy(m->g0);
     if (m->g1) (void)hipEventDestroy(m->g1);
     delete m;
@@ -126,17 +128,39 @@ int vv_mgpu_generate_default_brain(vv_mgpu *m, int vtype, int nx, int ny, int nz
 int vv_mgpu_stream_volume_u8(vv_mgpu *m, const uint8_t *t, int vtype, int nx, int ny, int nz, int per, const float tf[1024])
 {
     if (!m || !t || per < 1) return mfail(m, VV_ERR_INVALID, "vv_mgpu_stream_volume_u8: bad argument");
-    // every device takes the slabs in turn: the copies of one device overlap the promotion kernels of the others
     for (int r = 0; r < m->n; ++r) { int rc = vv_load_volume_stream_begin(m->ctx[r], vtype, nx, ny, nz, tf); if (rc) return mfail(m, rc, vv_last_error(m->ctx[r])); }
+    // Slab by slab: the slab is enqueued on EVERY device (each has its own PCIe link and copy engine), then the
+    // source reads are waited for -- not the promotion kernels, which overlap the next slab's copies.
     const size_t slice = (size_t)nx * ny;
-    for (int z = 0; z < nz; z += per) {
+    int rc = VV_OK, bad = -1;
+    for (int z = 0; z < nz && !rc; z += per) {
         const int n = z + per <= nz ? per : nz - z;
-        for (int r = 0; r < m->n; ++r) {
-            int rc = vv_load_volume_stream_slices(m->ctx[r], t + (size_t)z * slice, VV_VOXEL_U8, z, n);
-            if (rc) return mfail(m, rc, vv_last_error(m->ctx[r]));
-        }
+        for (int r = 0; r < m->n && !rc; ++r) { rc = vv_load_volume_stream_slices_async(m->ctx[r], t + (size_t)z * slice, VV_VOXEL_U8, z, n); if (rc) bad = r; }
+        for (int r = 0; r < m->n; ++r) { int r2 = vv_load_volume_stream_wait_source(m->ctx[r]); if (r2 && !rc) { rc = r2; bad = r; } }
     }
-    for (int r = 0; r < m->n; ++r) { int rc = vv_load_volume_stream_end(m->ctx[r]); if (rc) return mfail(m, rc, vv_last_error(m->ctx[r])); }
+    for (int r = 0; r < m->n; ++r) { int r2 = vv_load_volume_stream_end(m->ctx[r]); if (r2 && !rc) { rc = r2; bad = r; } }
+    if (rc) return mfail(m, rc, vv_last_error(m->ctx[bad < 0 ? 0 : bad]));
+    return VV_OK;
+}
+
+// Band bookkeeping of the gather (host arithmetic only; unit-tested without a GPU).  Band b = pixel rows
+// [56 b, 56 b + 56) belongs to rank b % n.  Of those rows a rank's vv_render writes the ones inside the slab-row range
+// [rb, re) of the options (0, 0 = all) and never row H-1 (kernel.cu:297-298); columns 0 .. W-2 of each.
+int vv_mgpu_band_rows(int H, int n, int slab_row_begin, int slab_row_end, int band, int *rank, int *y_begin, int *y_end)
+{
+    if (H < 1 || n < 1 || band < 0 || !rank || !y_begin || !y_end) return VV_ERR_INVALID;
+    const int band_px = kBand * kSlab, nbands = (H + band_px - 1) / band_px;
+    if (band >= nbands) return VV_ERR_INVALID;
+    const int nby = H / kSlab + ((H % kSlab) ? 1 : 0);
+    int rb = 0, re = nby;
+    if (!(slab_row_begin == 0 && slab_row_end == 0)) { rb = slab_row_begin; re = slab_row_end; }
+    if (rb < 0 || re > nby || rb > re) return VV_ERR_INVALID;
+    int ya = band * band_px, yb = ya + band_px;
+    if (ya < rb * kSlab) ya = rb * kSlab;
+    if (yb > re * kSlab) yb = re * kSlab;
+    if (yb > H - 1) yb = H - 1;                    // row H-1 is never written
+    if (yb < ya) yb = ya;
+    *rank = band % n; *y_begin = ya; *y_end = yb;
     return VV_OK;
 }
 
@@ -147,7 +171,8 @@ int vv_mgpu_render(vv_mgpu *m, int W, int H, const struct slice_params *slice, c
     if (!m || !rgba_out || W < 1 || H < 1) return mfail(m, VV_ERR_INVALID, "vv_mgpu_render: bad argument");
     const int n = m->n;
     const size_t fb = (size_t)W * H * 4, row = (size_t)W * 4;
-    // destination frame on device 0: the caller's buffer, or a staging frame seeded with the caller's bytes
+    // frames: rank r > 0 marches into its own full-size frame; device 0 holds the destination (the caller's buffer, or a
+    // staging frame seeded with the caller's bytes) and, for n > 1, a landing frame the bands are received into
     for (int r = 0; r < n; ++r) {
         const bool need = r > 0 || !out_on_device;
         if (need && m->frame_cap[r] < fb) {
@@ -158,38 +183,66 @@ int vv_mgpu_render(vv_mgpu *m, int W, int H, const struct slice_params *slice, c
             m->frame_cap[r] = fb;
         }
     }
+    if (n > 1 && m->land_cap < fb) {
+        MH(m, hipSetDevice(m->dev[0]));
+        if (m->land) MH(m, hipFree(m->land));
+        m->land = nullptr; m->land_cap = 0;
+        MH(m, hipMalloc((void **)&m->land, fb));
+        m->land_cap = fb;
+    }
     uint8_t *dst0 = out_on_device ? rgba_out : m->frame[0];
     MH(m, hipSetDevice(m->dev[0]));
     if (!out_on_device) MH(m, hipMemcpyAsync(dst0, rgba_out, fb, hipMemcpyHostToDevice, m->stream[0]));   // untouched pixels keep the caller's bytes
     // ---- march: every device its bands, all enqueued before anything is waited for ----
-    for (int r = 0; r < n; ++r) {
+    int rc = VV_OK;
+    std::string why;
+    for (int r = 0; r < n && !rc; ++r) {
         vv_render_options o;
         if (opts) o = *opts; else memset(&o, 0, sizeof o);
         if (n > 1) { o.shard_band = kBand; o.shard_count = n; o.shard_index = r; }
-        MH(m, hipSetDevice(m->dev[r]));
-        MH(m, hipEventRecord(m->e0[r], m->stream[r]));
-        int rc = vv_render(m->ctx[r], W, H, slice, cam, shading, rays, &o, r == 0 ? dst0 : m->frame[r], 1, (void *)m->stream[r]);
-        if (rc) return mfail(m, rc, std::string("vv_mgpu_render: rank ") + std::to_string(r) + ": " + vv_last_error(m->ctx[r]));
-        MH(m, hipEventRecord(m->e1[r], m->stream[r]));
+        if (hipSetDevice(m->dev[r]) != hipSuccess || hipEventRecord(m->e0[r], m->stream[r]) != hipSuccess) { rc = VV_ERR_DEVICE; why = "event record failed"; break; }
+        rc = vv_render(m->ctx[r], W, H, slice, cam, shading, rays, &o, r == 0 ? dst0 : m->frame[r], 1, (void *)m->stream[r]);
+        if (rc) { why = std::string("rank ") + std::to_string(r) + ": " + vv_last_error(m->ctx[r]); break; }
+        if (hipEventRecord(m->e1[r], m->stream[r]) != hipSuccess) { rc = VV_ERR_DEVICE; why = "event record failed"; }
     }
-    // ---- gather: band b (pixel rows [56 b, 56 b + 56)) belongs to rank b % n; one send / receive pair per band ----
-    MH(m, hipSetDevice(m->dev[0]));
-    MH(m, hipEventRecord(m->g0, m->stream[0]));
-    if (n > 1) {
+    // ---- gather: one send / receive pair per band of a rank > 0, whole pixel rows (contiguous) into the landing frame; then
+    //      only the pixels that rank wrote -- columns 0 .. W-2 of the rows vv_mgpu_band_rows() names -- go into the destination,
+    //      so column W-1 and row H-1 keep the caller's bytes (a rank's own frame is never seeded) ----
+    const int sr0 = opts ? opts->slab_row_begin : 0, sr1 = opts ? opts->slab_row_end : 0;
+    if (!rc && hipSetDevice(m->dev[0]) == hipSuccess) (void)hipEventRecord(m->g0, m->stream[0]);
+    if (!rc && n > 1) {
         const int band_px = kBand * kSlab, nbands = (H + band_px - 1) / band_px;
-        MN(m, ncclGroupStart());
-        for (int b = 0; b < nbands; ++b) {
-            const int r = b % n;
-            if (r == 0) continue;
-            const size_t y0 = (size_t)b * band_px, rows = (y0 + band_px <= (size_t)H ? band_px : H - y0), bytes = rows * row;
-            MN(m, ncclSend(m->frame[r] + y0 * row, bytes, ncclUint8, 0, m->comm[r], m->stream[r]));
-            MN(m, ncclRecv(dst0 + y0 * row, bytes, ncclUint8, r, m->comm[0], m->stream[0]));
+        ncclResult_t nr = ncclGroupStart();
+        bool open = nr == ncclSuccess;
+        for (int b = 0; b < nbands && nr == ncclSuccess; ++b) {
+            int r, ya, yb;
+            if (vv_mgpu_band_rows(H, n, sr0, sr1, b, &r, &ya, &yb) != VV_OK) { rc = VV_ERR_INVALID; why = "slab row range out of bounds"; break; }
+            if (r == 0 || yb <= ya) continue;
+            const size_t off = (size_t)ya * row, bytes = (size_t)(yb - ya) * row;
+            nr = ncclSend(m->frame[r] + off, bytes, ncclUint8, 0, m->comm[r], m->stream[r]);
+            if (nr == ncclSuccess) nr = ncclRecv(m->land + off, bytes, ncclUint8, r, m->comm[0], m->stream[0]);
         }
-        MN(m, ncclGroupEnd());
+        if (open) { ncclResult_t ne = ncclGroupEnd(); if (nr == ncclSuccess) nr = ne; }      // a group is never left open
+        if (nr != ncclSuccess && !rc) { rc = VV_ERR_DEVICE; why = std::string("RCCL: ") + ncclGetErrorString(nr); }
+        if (!rc && W >= 2) {
+            if (hipSetDevice(m->dev[0]) != hipSuccess) { rc = VV_ERR_DEVICE; why = "hipSetDevice failed"; }
+            for (int b = 0; b < nbands && !rc; ++b) {
+                int r, ya, yb;
+                (void)vv_mgpu_band_rows(H, n, sr0, sr1, b, &r, &ya, &yb);
+                if (r == 0 || yb <= ya) continue;
+                if (hipMemcpy2DAsync(dst0 + (size_t)ya * row, row, m->land + (size_t)ya * row, row, (size_t)(W - 1) * 4, (size_t)(yb - ya),
+                                     hipMemcpyDeviceToDevice, m->stream[0]) != hipSuccess) { rc = VV_ERR_DEVICE; why = "band copy failed"; }
+            }
+        }
     }
-    MH(m, hipEventRecord(m->g1, m->stream[0]));
-    if (!out_on_device) MH(m, hipMemcpyAsync(rgba_out, dst0, fb, hipMemcpyDeviceToHost, m->stream[0]));
-    for (int r = n - 1; r >= 0; --r) { MH(m, hipSetDevice(m->dev[r])); MH(m, hipStreamSynchronize(m->stream[r])); }
+    if (!rc && hipSetDevice(m->dev[0]) == hipSuccess) (void)hipEventRecord(m->g1, m->stream[0]);
+    if (!rc && !out_on_device && hipMemcpyAsync(rgba_out, dst0, fb, hipMemcpyDeviceToHost, m->stream[0]) != hipSuccess) { rc = VV_ERR_DEVICE; why = "read-back failed"; }
+    // every stream is drained on every path: nothing of this frame is in flight when the call returns
+    for (int r = n - 1; r >= 0; --r) {
+        if (hipSetDevice(m->dev[r]) != hipSuccess || hipStreamSynchronize(m->stream[r]) != hipSuccess) { if (!rc) { rc = VV_ERR_DEVICE; why = "stream synchronisation failed"; } }
+    }
+    (void)hipGetLastError();
+    if (rc) return mfail(m, rc, "vv_mgpu_render: " + why);
     return VV_OK;
 }
 

@@ -216,17 +216,6 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                 fetch_any<VOXEL, TEX8>(V, tx[u], ty[u], tz[u], C[u]);
             }
             __builtin_amdgcn_sched_barrier(0);           // all 4U gathers are issued before the first is consumed
-#if defined(VV_X_NOALU) && !defined(VV_ZPAIR)
-            // experiment build (tools/decompose.sh): keep the gathers, drop classification and blending
-            if constexpr (VOXEL == VV_VOXEL_F32) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    float v = ((C[u].a.x + C[u].b.x) + (C[u].c.x + C[u].d.x)) + ((C[u].a.y + C[u].b.y) + (C[u].c.y + C[u].d.y));
-                    res_r += (i0 + u <= n) ? v * 1e-30f : 0.f;
-                }
-                continue;
-            }
-#endif
             uint32_t idx[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) idx[u] = classify_index<VOXEL>(C[u], tx[u], ty[u], tz[u]);
@@ -287,6 +276,203 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 }
 
 // ---------------------------------------------------------------------------
+// march_skew_kernel: march_kernel with a per-lane sample offset ("skewed lock step").
+//
+// The reference's sample shells are spheres about a point that is not the eye (DESIGN.md pin 1), so the lanes of a
+// wave at the SAME sample index sit on different volume slices (C3: 3 slices apart in the median 32 x 2 wave, 6 at the
+// 90th percentile, more where a tile straddles the cube's silhouette).  A wave therefore keeps several slices' worth of
+// cache lines live per gather, and the L2 (4 MiB per XCD, shared by 64 such blocks) turns over before neighbouring
+// lanes and waves have used them (profiles/r03_traffic_split.txt).  Here lane L takes sample s = t - o_L at wave step t,
+// o_L = round((c_L - c_ref) / dc_L) with c the lane's first sample position along the march axis in voxels: the wave's
+// samples of one step lie within about one sample spacing of a common slice.  Every lane executes exactly the
+// reference's sequence of operations for its ray (chunks of 30, running position sums, the ERT rule); only WHEN a lane
+// does them changes, so frames and sample counts stay bit-identical for any offsets.
+// ---------------------------------------------------------------------------
+constexpr int kSkewMax = 30;
+template <int SLICE, int VOXEL, bool TEX8, bool GRAY, bool INSTR, int U>
+__global__ __launch_bounds__(256) void march_skew_kernel(FrameParams P, VolumeView V,
+                                                         const float4 *__restrict__ tf,
+                                                         const float *__restrict__ rad,
+                                                         uint32_t *__restrict__ pixels,
+                                                         unsigned long long *__restrict__ counter,
+                                                         uint32_t *__restrict__ bricks, StripMap M)
+{
+    __shared__ float lds_tf[1024];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ntx = (P.W + 31) >> 5;
+    int strip, tile_x;
+    if (M.xcd_band > 0) {
+        const int L = blockIdx.x, per_band = ntx * M.xcd_band;
+        const int xcd = L & 7, j = L >> 3;
+        const int band = (j / per_band) * 8 + xcd, w = j % per_band;
+        strip = band * M.xcd_band + w / ntx; tile_x = w % ntx;
+    } else { strip = blockIdx.x / ntx; tile_x = blockIdx.x % ntx; }
+    const int tw = M.tile_log2w, th = 6 - tw;
+    const int wx = wave & ((32 >> tw) - 1), wy = wave >> (5 - tw);
+    const int x = (tile_x << 5) + (wx << tw) + (lane & ((1 << tw) - 1));
+    const int y = M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * 8 + (wy << th) + (lane >> tw);
+    if (strip >= M.n_strips) return;                       // block-uniform, before any barrier
+    stage_tf_planar(lds_tf, tf);
+    const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax = P.H >= 2 ? P.H - 2 : 0;
+    const bool in_frame = x <= xmax && y <= ymax && row_owned(P, y);
+
+    float res_r = 0.f, res_g = 0.f, res_b = 0.f, res_a = 0.f;
+    unsigned long long executed = 0, slots = 0;
+    bool write_zero = false;
+
+    Ray r;
+    bool alive = false;
+    if (in_frame) {
+        f3 front, back;
+        ray_endpoints(P, x, y, front, back);
+        float length = vlen3(back.x - front.x, back.y - front.y, back.z - front.z);
+        if (length < 0.001f) {
+            write_zero = true;                                       // kernel.cu:334-338
+        } else {
+            float rd;
+            if (P.W < 2 || P.H < 2) {
+                rd = vlen3(front.x - P.cam_pos[0], front.y - P.cam_pos[1], front.z - P.cam_pos[2]);
+            } else {
+                int ox = owner_slab(x, P.W, P.nbx, P.conflict_x), oy = owner_slab(y, P.H, P.nby, P.conflict_y);
+                rd = rad[oy * P.nbx + ox];
+            }
+            setup_ray(P, front, back, rd, r);
+            alive = !r.cut_return;
+        }
+    }
+    if (!alive) { r.upper = -1.f; r.dist0 = 0.f; r.sstep = 1.f; r.origin = mk3(0, 0, 0); r.dir = r.origin; r.sdir = r.origin; }
+
+    // ---- the lane's offset (speed only: any value gives the same pixels) ----
+    int o = 0;
+    {
+        const bool az = M.skew_axis == 2;
+        const float isc = az ? P.inv_scale[2] : P.inv_scale[1], nn = az ? (float)V.nz : (float)V.ny;
+        const float p1 = (az ? r.origin.z + r.dir.z * r.dist0 + r.sdir.z : r.origin.y + r.dir.y * r.dist0 + r.sdir.y);
+        const float c = __builtin_fmaf(p1 - 0.5f, isc, 0.5f) * nn;           // first sample, in voxels along the march axis
+        const float dc = (az ? r.sdir.z : r.sdir.y) * isc * nn;              // voxels per sample (signed)
+        const bool fwd = alive && dc > 0.f, bwd = alive && dc < 0.f;
+        float cref = 0.f;
+        bool ok = false;
+        if (__any(fwd) && !__any(bwd)) {
+            float m = fwd ? c : INFINITY;
+            for (int q = 32; q > 0; q >>= 1) m = fminf(m, __shfl_xor(m, q));
+            cref = m; ok = fwd;
+        } else if (__any(bwd) && !__any(fwd)) {
+            float m = bwd ? c : -INFINITY;
+            for (int q = 32; q > 0; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
+            cref = m; ok = bwd;
+        }
+        if (ok) {
+            const float q = rintf((c - cref) / dc);                          // >= 0 for both directions
+            o = q >= 0.f ? (q < (float)kSkewMax ? (int)q : kSkewMax) : 0;    // (NaN -> 0)
+        }
+    }
+
+    float dist = r.dist0;
+    bool ert = false, stop = false, active = alive, lastc = false;
+    int i = 31 - o;              // the lane's next sample index within its chunk; 31 = "open the next chunk now"
+    int n = 0, chunks = 0;       // samples of the open chunk (0: none open / ray finished), chunks opened so far
+    float px = 0.f, py = 0.f, pz = 0.f;
+    const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
+    const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
+    const int tmax = P.max_chunks * 30 + kSkewMax + U;                       // wave-uniform bound: every wave exits
+
+    for (int t = 0; t < tmax; t += U) {
+        // a lane has samples left unless its ray never started, its last chunk ended short (kernel.cu:255-257: the next
+        // `while (dist < upper)` fails) or it terminated for good
+        const bool pending = active && !(lastc && i > n) && !(P.ert_true && ert);
+        if (!__any(pending)) break;
+        if (INSTR) slots += (unsigned long long)U * 64ull;
+        float tx[U], ty[U], tz[U], du[SLICE == SLICE_PLANE ? U : 1];
+        int iu[U];
+        bool lv[U];
+        typename CornerSel<VOXEL>::type C[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // ---- chunk boundary of this lane: close the old one (:277), open the next (:248-249) ----
+            if (__any(i == 31)) {
+                if (i == 31) {
+#pragma clang fp contract(off)
+                    if (chunks > 0) { dist += r.sstep * kChunkSteps; if (P.ert_true && ert) r.upper = -1.f; }
+                    i = 1; n = 0;
+                    if (active) {
+                        if (chunks >= P.max_chunks) active = false;
+                        else {
+                            n = chunk_count(dist, r.upper, r.sstep);
+                            lastc = n < 30;                                  // the `while (dist < upper)` after this chunk fails
+                            // pin 4 (speed only here: `stop` masks the same samples; `ert` may still miss a hit of this trip)
+                            if (ert && P.alpha_unit) n = min(n, 1);
+                            px = r.origin.x + r.dir.x * dist; py = r.origin.y + r.dir.y * dist; pz = r.origin.z + r.dir.z * dist;
+                            ++chunks;
+                            if (n == 0) active = false;                      // !(dist < upper), or the first sample already beyond it
+                        }
+                    }
+                }
+            }
+            px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;                  // :141
+            tx[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
+            ty[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
+            tz[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
+            fetch_any<VOXEL, TEX8>(V, tx[u], ty[u], tz[u], C[u]);
+            if (SLICE == SLICE_PLANE) du[u] = dist;
+            iu[u] = i; lv[u] = i <= n;                                       // (n == 0 while the lane idles before its first chunk / after its last)
+            ++i;
+        }
+        __builtin_amdgcn_sched_barrier(0);           // all 4U gathers are issued before the first is consumed
+        uint32_t idx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) idx[u] = classify_index<VOXEL>(C[u], tx[u], ty[u], tz[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // `stop` is the inner loop's break (:272-274), one flag per chunk: it is cleared where a chunk's first sample is
+            // consumed, not where the chunk was opened (samples of the old chunk in this trip are consumed after that point).
+            // VV_ERT_TRUE: a terminated ray takes no further sample at all.
+            if (iu[u] == 1) stop = false;
+            const bool live = lv[u] && !stop && !(P.ert_true && ert);
+            float cr, cg, cb, ca;
+            ca = lds_tf[768 + idx[u]];
+            cr = lds_tf[idx[u]];
+            if (GRAY) { cg = cb = cr; }
+            else { cg = lds_tf[256 + idx[u]]; cb = lds_tf[512 + idx[u]]; }
+            if (SLICE == SLICE_PLANE) {                                              // :193-198
+#pragma clang fp contract(off)
+                float vd = (float)iu[u] * r.sstep + du[u];                           // :254 (the dist of this sample's chunk)
+                float vx = r.origin.x + r.dir.x * vd, vy = r.origin.y + r.dir.y * vd, vz = r.origin.z + r.dir.z * vd;
+                float d = fabsf(sn.x * (vx - sp.x) + sn.y * (vy - sp.y) + sn.z * (vz - sp.z));
+                if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
+            }
+            if (INSTR) {
+                if (live) {
+                    executed++;
+                    if (bricks && bounds_check(tx[u], ty[u], tz[u])) mark_bricks(bricks, V, tx[u], ty[u], tz[u]);
+                }
+            }
+            {
+#pragma clang fp contract(off)
+                const float bf = (live && ca > kEps) ? ca * (1.f - res_a) : 0.f;
+                res_r = res_r + cr * bf;
+                if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
+                res_a = res_a + bf;
+            }
+            const bool hit = live && res_a > P.ert_thr;                              // :272-274
+            stop = stop || hit;
+            ert = ert || hit;
+        }
+    }
+
+    if (in_frame) {
+        if (GRAY) { res_g = res_r; res_b = res_r; }
+        pixels[(size_t)y * P.W + x] = write_zero ? 0u : pack_rgba(res_r, res_g, res_b, res_a);
+    }
+    if (INSTR) {
+        for (int q = 32; q > 0; q >>= 1) executed += __shfl_down(executed, q);
+        if (lane == 0 && executed) atomicAdd(counter, executed);
+        if (lane == 0 && slots) atomicAdd(counter + 1, slots);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // march_phong_kernel: one block per reference slab (14x14 interior + apron),
 // 32-deep byte cache in LDS exactly as kernel.cu:125-145 lays it out, but indexed
 // by thread (so clamped apron threads own private entries with identical content).
@@ -294,16 +480,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 // thread keeps marching its own chunk sequence until the whole block is done, so
 // neighbour entries are never stale (pin 5).
 // ---------------------------------------------------------------------------
-// SPB x-adjacent slabs per block (256 threads each, own apron, own `rad`, own LDS cache): a slab's footprint is 16
-// pixels wide, about one 128-byte line of voxels that mostly straddles two; neighbouring slabs marched by the same
-// block at the same time find each other's lines in L1 (measured: the one-slab form moves 2.8x the algorithmic bytes).
-//
-// COMPACT: the cache refresh (the gathers) is dealt to the lanes as (needed ray, quarter of its 32 entries) work items
-// instead of "every thread refreshes its own 32".  A ray's entries are needed in a chunk only if it or one of the four
-// rays that look at it composites in that chunk (the reference refreshes all 256: its apron corners, rays that have
-// terminated, rays that miss the volume and their far neighbours are refreshed and never read).  Values and addresses
-// of the entries that are read are unchanged, so frames stay bit-identical.
-template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB, bool COMPACT>
+template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 // Registers: on the linear layout up to 4 GiB the kernel is compiled for 5 waves per SIMD (83-85 VGPRs: the volumes that
 // live in the caches want 5 blocks per CU; C1 0.196 -> 0.174 ms, 256^3 1.36 -> 1.28); the variants for volumes beyond
 // 4 GiB and for the bricked copy run 2-3 blocks per CU and are 2-7 % faster with the 106 VGPRs the compiler takes by itself.
@@ -312,38 +489,21 @@ template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB, bool COMPACT>
 #else
 #define VV_PHONG_OCC __attribute__((amdgpu_waves_per_eu(5)))
 #endif
-__global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(FrameParams P, VolumeView V,
+__global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FrameParams P, VolumeView V,
                                                           const float4 *__restrict__ tf, SlabMap M,
                                                           uint32_t *__restrict__ pixels,
                                                           unsigned long long *__restrict__ counter,
                                                           uint32_t *__restrict__ bricks)
 {
     __shared__ float4 lds_tf[256];
-    __shared__ float red_[SPB][256];
-    __shared__ uint8_t cache_[SPB][kCacheDepth][256];
+    __shared__ float red[256];
+    __shared__ uint8_t cache[kCacheDepth][256];
     __shared__ float q255[256];              // q / 255.f for every byte q, by the same IEEE division
     __shared__ int any_live;
-    // COMPACT: chunk start position and step of every ray, who needs a refresh, and the packed list of those
-    __shared__ float pos0_[COMPACT ? 6 : 1][COMPACT ? SPB * 256 : 1];
-    __shared__ uint8_t need_[COMPACT ? SPB * 256 : 1], mine_[(COMPACT && INSTR) ? SPB * 256 : 1];
-    __shared__ uint16_t list_[COMPACT ? SPB * 256 : 1];
-    __shared__ int wtot_[4 * SPB];
-    // thread -> (slab of the block, thread of the slab).  One slab per block: a wave is 16 x 4 threads of it.  Several:
-    // a wave is 32 x 2 threads across two x-adjacent slabs, so its gathers touch the same two or three whole lines per
-    // voxel row that march_kernel's 32 x 2 wave tiles do instead of 1-2 half-used ones (the slabs keep their own
-    // apron, `rad` and cache: only which lane marches which ray changes)
-    int tid, sub;
-    if (SPB == 1) { tid = threadIdx.x; sub = 0; }
-    else {
-        const int w = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
-        sub = (w % (SPB / 2)) * 2 + ((l & 31) >> 4);
-        tid = ((w / (SPB / 2)) * 2 + (l >> 5)) * 16 + (l & 15);
-    }
-    float *red = red_[sub];
-    uint8_t (*cache)[256] = cache_[sub];
+    const int tid = threadIdx.x;
     // XCD-aware order (speed only, as in march_kernel): linear block L runs on XCD L % 8; XCD k takes the
     // grid rows k, k+8, ... so that the slabs of one row, which share volume lines, share an L2
-    const int nbxg = (P.nbx + SPB - 1) / SPB;
+    const int nbxg = P.nbx;
 #ifndef VV_PHONG_BAND
 #define VV_PHONG_BAND 1
 #endif
@@ -354,15 +514,12 @@ __global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(Fra
     stage_tf(lds_tf, tf);
     // kernel.cu:175-177 divides six cached bytes by 255.f per shaded sample; a correctly rounded
     // division is ~10 instructions, a table look-up of the same quotient is one LDS read
-    if (sub == 0) q255[tid] = (float)tid / 255.f;        // visible after the barriers of the reduction below
+    q255[tid] = (float)tid / 255.f;                      // visible after the barriers of the reduction below
 
     // grid row gy -> slab row of this shard; the last grid row is the "extra" slab row
     // nby-1 that re-writes pixel row H-2 when H == 1 (mod 14) (pin 10): it travels with
     // the shard that owns pixel row H-2.
-    // the block's slabs gx*SPB .. gx*SPB+SPB-1 of the slab row; one beyond the row's end marches a ghost copy of the
-    // last slab (it keeps the barriers in step) and writes nothing
-    const bool ghost = gx * SPB + sub >= P.nbx;
-    const int bx = ghost ? P.nbx - 1 : gx * SPB + sub;
+    const int bx = gx;
     int by;
     if (gy == M.n_regular) { if (!P.conflict_y) return; by = P.nby - 1; }
     else by = M.r0 + (gy / M.band) * M.band_stride + (gy % M.band);
@@ -399,7 +556,7 @@ __global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(Fra
 
     // write ownership (pin 10) and one writer per pixel
     const int ox = owner_slab(x, P.W, P.nbx, P.conflict_x), oy = owner_slab(y, P.H, P.nby, P.conflict_y);
-    bool writer = !border && ox == bx && oy == by && !ghost;
+    bool writer = !border && ox == bx && oy == by;
     // among interior threads clamped onto the same pixel keep the one whose unclamped
     // coordinate equals the pixel, or (pin 10 case: none does) the first interior one
     {
@@ -427,12 +584,6 @@ __global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(Fra
     const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
     const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
 
-    const int g = sub * 256 + tid;                     // this thread's ray within the block
-    if (COMPACT) {
-        need_[g] = 0;
-        pos0_[3][g] = r.sdir.x; pos0_[4][g] = r.sdir.y; pos0_[5][g] = r.sdir.z;
-        __syncthreads();
-    }
     for (int chunk = 0; chunk < P.max_chunks; ++chunk) {
         bool mine = marching && !ert_done && dist < r.upper;
         // How deep this chunk's cache has to be: a compositing ray reads its entries 0 .. n+1 and its neighbours' 1 .. n,
@@ -442,7 +593,7 @@ __global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(Fra
         // fl(r + fl(c * fl(1 - r))) <= 1 for r, c in [0, 1]).  The block refreshes the deepest need of its rays -- the
         // reference refreshes all 32 always (:125-145); entries nobody reads are not observable.
         int depth = kCacheDepth;
-        if (!COMPACT) {
+        {
             int d = 0;
             if (mine) {
 #pragma clang fp contract(off)
@@ -469,68 +620,6 @@ __global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(Fra
             depth = any_live;
             if (!depth) break;
         }
-        if (COMPACT) {
-            constexpr int NT = 256 * SPB, NW = 4 * SPB;
-            {
-#pragma clang fp contract(off)
-                pos0_[0][g] = r.origin.x + r.dir.x * dist; pos0_[1][g] = r.origin.y + r.dir.y * dist; pos0_[2][g] = r.origin.z + r.dir.z * dist;
-            }
-            if (INSTR) mine_[g] = mine;
-            // need_ is all zero here (cleared before the loop, or by its readers in the last chunk, barriers in between)
-            if (mine) { const int b = sub * 256; need_[g] = 1; need_[b + nl] = 1; need_[b + nr] = 1; need_[b + nt] = 1; need_[b + nb] = 1; }
-            __syncthreads();
-            // pack the needed rays in thread order (neighbouring lanes keep neighbouring rays)
-            const bool nd = need_[g] != 0;
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(nd);
-            const int wv = (int)threadIdx.x >> 6;
-            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-            if ((threadIdx.x & 63) == 0) wtot_[wv] = __builtin_popcountll(bal);
-            need_[g] = 0;                         // only this thread reads its flag
-            __syncthreads();
-            int off = 0, n = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) { const int c = wtot_[w]; off += w < wv ? c : 0; n += c; }
-            if (n == 0) break;                    // block-uniform
-            if (nd) list_[off + rank] = (uint16_t)g;
-            __syncthreads();
-            const int n_items = n * 4;
-            constexpr int PU = 4;
-            for (int base = 0; base < n_items; base += NT) {
-                const int item = base + (int)threadIdx.x;
-                if (item < n_items) {
-                    const int q = (item >= n) + (item >= 2 * n) + (item >= 3 * n);
-                    const int gg = list_[item - q * n];
-                    uint8_t (*cq)[256] = cache_[gg >> 8];
-                    const int tt = gg & 255;
-                    float px = pos0_[0][gg], py = pos0_[1][gg], pz = pos0_[2][gg];
-                    const float sx = pos0_[3][gg], sy = pos0_[4][gg], sz = pos0_[5][gg];
-                    for (int k = 0; k < q * 8; ++k) { px += sx; py += sy; pz += sz; }     // the reference's running sum (:139-141)
-                    const bool mk = INSTR && bricks && mine_[gg];
-#pragma unroll 1
-                    for (int i0 = q * 8; i0 < q * 8 + 8; i0 += PU) {
-                        float tx_[PU], ty_[PU], tz_[PU];
-                        typename CornerSel<VOXEL>::type C[PU];
-#pragma unroll
-                        for (int u = 0; u < PU; ++u) {
-                            tx_[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
-                            ty_[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
-                            tz_[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-                            fetch_any<VOXEL, TEX8>(V, tx_[u], ty_[u], tz_[u], C[u]);
-                            px += sx; py += sy; pz += sz;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < PU; ++u) {
-                            const int i = i0 + u;
-                            cq[i][tt] = (uint8_t)classify_index<VOXEL>(C[u], tx_[u], ty_[u], tz_[u]);
-                            if (INSTR && mk && i >= 1 && i <= 30 && bounds_check(tx_[u], ty_[u], tz_[u])) mark_bricks(bricks, V, tx_[u], ty_[u], tz_[u]);
-                        }
-                    }
-                }
-            }
-            if (INSTR && threadIdx.x == 0) atomicAdd(counter + 1, (unsigned long long)n * kCacheDepth);   // entries refreshed
-            if (INSTR && threadIdx.x == 0) atomicAdd(counter + 8 + min((n - 1) / (32 * SPB), 7), 1ull);         // histogram of needed rays per chunk
-        } else
         // rayMarch: every thread refreshes its 32 cache entries for this chunk  :125-145
         {
             float px, py, pz;
@@ -549,12 +638,7 @@ __global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(Fra
 #endif
 #endif
             constexpr int PU = VV_PHONG_PU;
-#ifdef VV_X_PHONG_NOFETCH                // decomposition build (tools/decompose_phong.sh): no gathers, pixels are wrong
-            for (int i = 0; i < kCacheDepth; ++i) cache[i][tid] = (uint8_t)((tid * 7 + i * 13 + chunk) & 255);
-            for (int i0 = 0; i0 < 0; i0 += PU) {
-#else
-            for (int i0 = 0; i0 < 1; i0 += PU) {
-#endif
+            {
                 auto refresh = [&](const int i0) {
                     float tx_[PU], ty_[PU], tz_[PU];
                     typename CornerSel<VOXEL>::type C[PU];
@@ -580,17 +664,7 @@ __global__ __launch_bounds__(256 * SPB) VV_PHONG_OCC void march_phong_kernel(Fra
             }
         }
         __syncthreads();
-#ifdef VV_X_PHONG_NOSHADE                // decomposition build: the gathers without the shading
         if (mine) {
-            uint32_t acc = 0;
-            for (int i = 1; i < kCacheDepth - 1; ++i) acc += cache[i][tid] + cache[i][nl];
-            res_r += (float)acc; res_a += 1e-4f;
-            if (res_a > P.ert_thr) ert_done = true;
-        }
-        if (false) {
-#else
-        if (mine) {
-#endif
             for (int i = 1; i < kCacheDepth - 1; ++i) {
 #pragma clang fp contract(off)
                 float vd = (float)i * r.sstep + dist;                                 // :254
@@ -662,6 +736,18 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
     dim3 grid(nblocks);
     // a.lds_reserve bytes of (unused) dynamic LDS cap the number of resident blocks per CU:
     // fewer waves share the 32 KB L1, which this gather kernel needs more than latency hiding
+    if (a.strips.skew_axis) {
+        if (a.unroll == 3)
+            hipLaunchKernelGGL((march_skew_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 3>), grid, dim3(256), (size_t)a.lds_reserve, s,
+                               a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
+        else if (a.unroll == 1)
+            hipLaunchKernelGGL((march_skew_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 1>), grid, dim3(256), (size_t)a.lds_reserve, s,
+                               a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
+        else
+            hipLaunchKernelGGL((march_skew_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 2>), grid, dim3(256), (size_t)a.lds_reserve, s,
+                               a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
+        return;
+    }
     if (a.unroll == 3)
         hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 3>), grid, dim3(256), (size_t)a.lds_reserve, s,
                            a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
@@ -669,25 +755,14 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
         hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 2>), grid, dim3(256), (size_t)a.lds_reserve, s,
                            a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
 }
-template <int SLICE, int VOXEL, bool TEX8, bool INSTR, int SPB, bool COMPACT>
-static void launch_phong_spb(const MarchArgs &a, hipStream_t s)
-{
-    const int rows = a.slabs.n_regular + 1;                   // grid rows, dealt to the 8 XCDs round-robin
-    constexpr int BAND = VV_PHONG_BAND;
-    dim3 grid((unsigned)(((rows + 8 * BAND - 1) / (8 * BAND)) * 8 * BAND * ((a.P.nbx + SPB - 1) / SPB)));
-    hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR, SPB, COMPACT>), grid, dim3(256 * SPB), (size_t)a.lds_reserve_phong, s,
-                       a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
-}
 template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 static void launch_phong(const MarchArgs &a, hipStream_t s)
 {
-    if (a.phong_compact) {
-        if (a.phong_spb == 2) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 2, true>(a, s);
-        else launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 1, true>(a, s);
-    } else {
-        if (a.phong_spb == 2) launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 2, false>(a, s);
-        else launch_phong_spb<SLICE, VOXEL, TEX8, INSTR, 1, false>(a, s);
-    }
+    const int rows = a.slabs.n_regular + 1;                   // grid rows, dealt to the 8 XCDs round-robin
+    constexpr int BAND = VV_PHONG_BAND;
+    dim3 grid((unsigned)(((rows + 8 * BAND - 1) / (8 * BAND)) * 8 * BAND * a.P.nbx));
+    hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), (size_t)a.lds_reserve_phong, s,
+                       a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
 }
 
 template <int SLICE, int VOXEL, bool TEX8>

@@ -56,7 +56,6 @@ struct Ctl {                                   // control block in LDS
     i2v tab[kTab];                            // per slice k (entry k % kTab): byte address of voxel (x 0, row 0) of its image, row pitch
     int box[kTab][4];                          // per slice: x0, x1, r0, r1 held (instrumented builds check against it)
     int owner[kPages + 2];                     // per ring page: the slice whose image occupies it
-    int sink[64];                              // where the prefetch wave's 4-byte loads land
     int dbg[4][8];                             // debug builds: what each loader wave is doing
 };
 static_assert(sizeof(Ctl) <= kCtlBytes, "control block");
@@ -195,43 +194,6 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         const uint64_t Ss = MAJOR == 2 ? V.slice_bytes : V.row_bytes;       // bytes between slices
         __syncthreads();
         const int kmin = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmin)), kmax = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmax));
-        if (lw >= S.nl) {
-            // ---- prefetch wave (optional): pulls the footprints of the slices ahead of the loaders from HBM into the
-            // XCD's L2, one 4-byte load per 128-byte line into a sink in LDS (no destination register that a late
-            // load could clobber), so that a ring fill lands in a few hundred cycles instead of thousands. ----
-            int kp = kmin, idle = 0;
-            while (kp <= kmax) {
-                const i4v l4 = lds_load_i4(ctl->landed);
-                const int ld = __builtin_amdgcn_readfirstlane(min(min(l4.x, l4.y), min(l4.z, l4.w)));
-                if (ld >= kInf) break;
-                if (kp >= ld + S.lead) {
-                    if ((++idle & 15) == 0 && __builtin_amdgcn_readlane(row16_min(lds_load_i(&ctl->progress[lane & 15])), 15) >= kInf) break;
-                    if (idle > (1 << 22)) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
-                }
-                idle = 0;
-                const int s = kmul * kp + kadd;
-                Foot f = footprint(FL, s, nx, nr);
-                f.x0 = __builtin_amdgcn_readfirstlane(f.x0); f.x1 = __builtin_amdgcn_readfirstlane(f.x1);
-                f.r0 = __builtin_amdgcn_readfirstlane(f.r0); f.r1 = __builtin_amdgcn_readfirstlane(f.r1);
-                const int c0 = f.x0 >> 5, ncell = min((f.x1 >> 5) - c0 + 1, S.pxc), nrows = min(f.r1 - f.r0 + 1, S.ry);
-                const char *g0 = (const char *)V.data + (uint64_t)s * Ss + (uint64_t)f.r0 * Sr + (uint64_t)c0 * 128u;
-                const int lc = lane & 7, lr = lane >> 3;                 // lane l: line (l % 8) of row (l / 8), 8 rows per instruction
-                if (lc < ncell) {
-                    for (int r0 = 0; r0 < nrows; r0 += 8) {
-                        if (r0 + lr < nrows) {
-                            const char *g = g0 + (uint64_t)(r0 + lr) * Sr + (uint32_t)lc * 128u;
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                                             (__attribute__((address_space(3))) void *)ctl->sink, 4, 0, 0);
-                        }
-                    }
-                }
-                ++kp;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            return;
-        }
         // ---- loader wave lw: every nl-th group of `group` slices.  The ring is handed out in 1 KiB pages, in slice
         // order, as a circular first-in-first-out buffer: a group takes ceil(slices * rows * pitch / 1 KiB) pages at
         // `head`, or at page 0 when they do not fit before the end.  Every loader wave derives the same positions from
@@ -598,7 +560,7 @@ static void launch_one(const MarchArgs &a, hipStream_t s)
     auto kern = sweep_kernel<MAJOR, TEX8, GRAY, INSTR>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3((unsigned)((S.nc + S.nl + (S.lead > 0 ? 1 : 0)) * 64)), (size_t)S.lds_bytes, s,
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3((unsigned)((S.nc + S.nl) * 64)), (size_t)S.lds_bytes, s,
                        a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, S);
 }
 template <int MAJOR>
@@ -704,11 +666,7 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     if (req.wy >= 1 && req.wy <= 14) S.wy = req.wy;
     S.group = 3;                             // slices per allocation / confirmation unit of the loaders
     if (req.group >= 1 && req.group <= 8) S.group = req.group;
-    S.depth = 2;                             // groups a loader wave keeps pending before it waits for the oldest
-    if (req.depth >= 1 && req.depth <= 8) S.depth = req.depth;
-    S.lead = 0;                              // slices the prefetch wave runs ahead of the landed ones (0: no prefetch wave)
-    if (req.lead >= 0 && req.lead <= 64) S.lead = req.lead;
-    if (S.wx * S.wy + S.nl + (S.lead > 0 ? 1 : 0) > 16) VV_NO("too many waves");
+    if (S.wx * S.wy + S.nl > 16) VV_NO("too many waves");
     const bool forced = req.wx >= 1 || req.wy >= 1;
     for (;;) {
         S.nc = S.wx * S.wy;

@@ -80,6 +80,7 @@ EXPORTS = [
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
     "vv_prepare_layouts", "vv_device_bytes", "vv_debug_sweep_trace", "vv_reread_env", "vv_debug_plan_sweep",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
+    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source",
 ]
 
 _lib = None
@@ -105,6 +106,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_set_transfer_function.argtypes = [vp, vp]
     lib.vv_load_volume_stream_begin.argtypes = [vp, i, i, i, i, vp]
     lib.vv_load_volume_stream_slices.argtypes = [vp, vp, i, i, i]
+    lib.vv_load_volume_stream_slices_async.argtypes = [vp, vp, i, i, i]
+    lib.vv_load_volume_stream_wait_source.argtypes = [vp]
     lib.vv_load_volume_stream_end.argtypes = [vp]
     lib.vv_load_volume_t3d.argtypes = [vp, C.c_char_p, i, i, vp]
     lib.vv_render.argtypes = [vp, i, i, C.POINTER(slice_params), C.POINTER(camera_params),
