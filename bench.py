@@ -246,7 +246,21 @@ def main():
     #      its steady state (MI355X, C3: frames 1-25 after the set-up take 1.05 ms, from about frame 50 on 1.00 ms --
     #      power state and translation caches; measured with --warmup 3 / 50 / 300).  A renderer runs in that steady state;
     #      the timed region is still exactly K complete frames.  VV_BENCH_SPINUP=0 disables it. ----
+    # The same K frames are first timed WITHOUT it (after the W warm-up steps only: what a driver calling `--warmup 5` would
+    # see from a cold device) and reported as `ms_per_step_first` / `roofline.frac_first`, so both readings are on record.
     spinup = int(os.environ.get("VV_BENCH_SPINUP", "300"))
+    cold_ms = None
+    if world == 1:
+        for _ in range(args.warmup):
+            ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong)
+        ce = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        for k in range(args.steps):
+            ce[k][0].record()
+            ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong)
+            ce[k][1].record()
+        torch.cuda.synchronize()
+        cold_ms = float(np.mean([a.elapsed_time(b) for a, b in ce]))
     for _ in range(spinup):
         ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong)
     torch.cuda.synchronize()
@@ -275,6 +289,17 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     frame = G.frames[(args.steps - 1) & 1]
+    # N > 1: the gathered frame is checked (untimed) against the same frame rendered unsharded on rank 0 -- a throughput
+    # number from a gather that scrambled or dropped bands would be worthless
+    gather_check = "n/a (single GPU)"
+    if world > 1 and rank == 0:
+        whole = torch.full_like(frame, 0)
+        whole.copy_(frame)                                  # pixels the frame never writes (column W-1, row H-1) compare equal
+        wo = vv.make_options(**{k: v for k, v in base.items() if k != "shard"})
+        ctx.render_device(W, H, cam, whole.data_ptr(), options=wo, stream=stream, phong=args.phong)
+        torch.cuda.synchronize()
+        nbad = int((whole[:H] != frame[:H]).any(dim=-1).sum().item())
+        gather_check = "ok" if nbad == 0 else f"mismatch ({nbad} of {H * W} pixels)"
     el = torch.tensor([t1 - t0], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -317,9 +342,14 @@ def main():
                    "sharding": "single GPU" if world == 1 else f"bands of {sharding.BAND_PX} pixel rows round-robin over {world} GPUs, volume replicated, 1 RCCL gather/frame"},
         "executed_samples_per_frame": int(samples_all), "upper_bound_samples_WxHxS": W * H * steps,
         "spinup_frames": spinup, "kernel_ms_rank0": round(kern_ms, 4), "kernel_ms_per_rank": kern_ranks,
+        "ms_per_step_first": None if cold_ms is None else round(cold_ms, 4),
         "collective": None if world == 1 else {"backend": backend, "ranks": nranks, "per_frame": "1 gather of RGBA8 bands to rank 0"},
+        "gather_check": gather_check,
         "roofline": {"bound": "hbm", "kernel": ("march_phong_kernel" if args.phong else "march_kernel (+rad_kernel)"), "achieved": round(achieved / 1e9, 1),
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
+                     "frac_first": None if cold_ms is None else round(bytes_rank / (cold_ms * 1e-3) / HBM_PEAK, 4),
+                     "protocol": f"frac: {args.steps} frames after {spinup} untimed spin-up frames + {args.warmup} warm-up (steady state); "
+                                 f"frac_first: the {args.steps} frames right after the {args.warmup} warm-up frames (device still ramping up)",
                      "traffic": traffic, "algorithmic_bytes_per_launch": int(bytes_rank),
                      "bytes_per_sample": round(bytes_rank / max(samples, 1), 3)},
     }
@@ -378,6 +408,7 @@ def main():
                 sN += O.render(c1_vol, c1_tf, 512, 512, c1_cam, threads=cores)[1]; reps += 1
             dt = time.perf_counter() - t
             out["cpu_baseline"] = {"value": round(sN / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                                   "workload": "C1 (BASELINE.md section 3) -- NOT the workload of `value` (C3); the port on C3 itself is `cpu_baseline_c3`",
                                    "ms_per_frame": round(dt / reps * 1e3, 2),
                                    "sample": f"config C1: {reps} x the whole 512x512 frame of the 128^3 drawDefaultBrain volume, Head TF, step 1/128 "
                                              f"({sN} samples in {dt:.1f} s; oracle/vvo.c, OpenMP, {cores} threads)"}

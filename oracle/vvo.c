@@ -93,6 +93,40 @@ void vvo_transfer_preset(int preset, float tf[1024])
 /* ============================================================================
  * helpers restating kernel.cu:53-71 and include/helper_math.h semantics
  * ========================================================================== */
+/* ----------------------------------------------------------------------------
+ * Arithmetic model.  VVO_MODEL 0 (the default, what every parity test uses) = the pins of
+ * DESIGN.md section 3, which the product implements bit for bit.  The other models are built
+ * into separate libraries (oracle/Makefile `models`) only to MEASURE how far frames move if
+ * the choices nobody can read off the CUDA build (nvcc 5.5, -use_fast_math, sm_21) went the
+ * other way -- tests/test_oracle_models.py; they are not parity targets:
+ *   1 FMAD     a*b+c contracted wherever the compiler can (nvcc's default --fmad=true): the
+ *              same source built with -ffp-contract=fast -mfma
+ *   2 FAST     FMAD + what -use_fast_math adds: x/y as x * rcp(y), sqrt(x) as x * rsqrt(x),
+ *              rsqrt(x) as rcp(sqrt(x)) (each step correctly rounded here; the hardware's
+ *              approximations are within 1-2 ulp of these), denormals flushed (FTZ/DAZ)
+ *   3 TEXTRUNC the texture unit's 8-bit interpolation weights truncated instead of rounded
+ * -------------------------------------------------------------------------- */
+#ifndef VVO_MODEL
+#define VVO_MODEL 0
+#endif
+#if VVO_MODEL == 2
+#include <xmmintrin.h>
+static inline float vvo_rcp(float y) { return 1.0f / y; }
+static inline float vvo_rsqrt(float x) { return vvo_rcp(sqrtf(x)); }
+#define FDIV(a, b) ((a) * vvo_rcp(b))
+#define FSQRT(x)   ((x) * vvo_rsqrt(x) == (x) * vvo_rsqrt(x) ? ((x) == 0.0f ? 0.0f : (x) * vvo_rsqrt(x)) : sqrtf(x))
+#define FRSQRT(x)  vvo_rsqrt(x)
+#else
+#define FDIV(a, b) ((a) / (b))
+#define FSQRT(x)   sqrtf(x)
+#define FRSQRT(x)  (1.0f / sqrtf(x))
+#endif
+const char *vvo_model(void)
+{
+    static const char *const names[] = {"pins", "fmad", "fast", "textrunc"};
+    return names[VVO_MODEL];
+}
+
 typedef struct { float x, y, z; } f3;
 
 static inline f3 mk3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
@@ -102,7 +136,7 @@ static inline f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z);
 static inline f3 scl3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; } /* helper_math.h dot */
 /* kernel.cu:53-57 vectorLength */
-static inline float vlen(f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+static inline float vlen(f3 v) { return FSQRT(v.x * v.x + v.y * v.y + v.z * v.z); }
 /* helper_math.h:1152-1155 clamp = fmaxf(a, fminf(f, b)) */
 static inline float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
 static inline int clampi(int f, int a, int b) { int m = f < b ? f : b; return a > m ? a : m; }
@@ -129,7 +163,11 @@ static inline void tex_axis(float x, int n, int filter, int *i0, int *i1, float 
     float xb = fmaf(x, (float)n, -0.5f);
     float fl = floorf(xb);
     float a = xb - fl;
+#if VVO_MODEL == 3
+    if (filter == VV_FILTER_TEX8) a = floorf(a * 256.0f) * (1.0f / 256.0f);  /* measurement model: truncated */
+#else
     if (filter == VV_FILTER_TEX8) a = rintf(a * 256.0f) * (1.0f / 256.0f);   /* ties to even */
+#endif
     int i = (int)fl;
     *i0 = clampi(i, 0, n - 1);
     *i1 = clampi(i + 1, 0, n - 1);
@@ -166,7 +204,7 @@ static inline float tex3d_raw(const vvo_volume *v, float x, float y, float z, in
 float vvo_tex3d(const vvo_volume *v, float x, float y, float z, int filter)
 {
     float L = tex3d_raw(v, x, y, z, filter);
-    return v->type == VV_VOXEL_U8 ? L / 255.0f : L;
+    return v->type == VV_VOXEL_U8 ? FDIV(L, 255.0f) : L;
 }
 
 /* float -> unsigned char conversion as the GPU does it: truncate toward zero,
@@ -415,7 +453,7 @@ static int intersect_plane_ray(f3 p0, f3 n, f3 l0, f3 l, float *t)
     float denom = dot3(n, l);
     if ((double)denom > 1e-6) {
         f3 p0l0 = sub3(p0, l0);
-        *t = dot3(p0l0, n) / denom;
+        *t = FDIV(dot3(p0l0, n), denom);
         return *t >= 0;
     }
     return 0;
@@ -428,7 +466,7 @@ static int intersect_sphere_ray(f3 p0, float r, f3 l0, f3 l, float *t)
     float c = dot3(l0p0, l0p0) - r * r;
     float discrim = b * b - c;
     if (discrim >= 0.f) {
-        *t = b * -1.f - sqrtf(discrim);
+        *t = b * -1.f - FSQRT(discrim);
         return (double)*t > -1e-6;
     }
     return 0;
@@ -480,7 +518,7 @@ static void setup_ray(const frame_t *F, f3 front, f3 back, float rad, ray_t *r)
 {
     f3 dist = sub3(back, front);
     float length = vlen(dist);
-    f3 ray = mk3(dist.x / length, dist.y / length, dist.z / length);  /* :340 (NaN if length==0) */
+    f3 ray = mk3(FDIV(dist.x, length), FDIV(dist.y, length), FDIV(dist.z, length));  /* :340 (NaN if length==0) */
     f3 pos = front;
     float t;
     if (intersect_sphere_ray(F->cam_pos, rad, front, scl3(ray, -1.f), &t))  /* :344 */
@@ -527,15 +565,15 @@ static void shade_voxel(const frame_t *F, const uint8_t *self, const uint8_t *co
     uint8_t s = get_voxel(self, offset);
     memcpy(value, F->tf + 4 * (int)s, 4 * sizeof(float));              /* :120-123 tex1Dfetch */
     if (F->phong && (double)value[3] > 1e-6) {                          /* :164 */
-        float f = get_voxel(self, offset - 1) / 255.f;                 /* :167 */
-        float a = get_voxel(self, offset + 1) / 255.f;                 /* :168 */
-        float l = get_voxel(nb[0], offset) / 255.f;                    /* :170 */
-        float r = get_voxel(nb[1], offset) / 255.f;                    /* :171 */
-        float t = get_voxel(nb[2], offset) / 255.f;                    /* :172 */
-        float b = get_voxel(nb[3], offset) / 255.f;                    /* :173 */
-        f3 g = mk3((r - l) / voxel_dim.x, (t - b) / voxel_dim.y, (a - f) / voxel_dim.z); /* :175-178 */
+        float f = FDIV((float)get_voxel(self, offset - 1), 255.f);                 /* :167 */
+        float a = FDIV((float)get_voxel(self, offset + 1), 255.f);                 /* :168 */
+        float l = FDIV((float)get_voxel(nb[0], offset), 255.f);                    /* :170 */
+        float r = FDIV((float)get_voxel(nb[1], offset), 255.f);                    /* :171 */
+        float t = FDIV((float)get_voxel(nb[2], offset), 255.f);                    /* :172 */
+        float b = FDIV((float)get_voxel(nb[3], offset), 255.f);                    /* :173 */
+        f3 g = mk3(FDIV(r - l, voxel_dim.x), FDIV(t - b, voxel_dim.y), FDIV(a - f, voxel_dim.z)); /* :175-178 */
         if (g.x != 0.f && g.y != 0.f && g.z != 0.f) {                   /* :180-181 */
-            float inv = 1.0f / sqrtf(dot3(g, g));                       /* helper_math.h:1309-1312 rsqrtf */
+            float inv = FRSQRT(dot3(g, g));                             /* helper_math.h:1309-1312 rsqrtf */
             g = scl3(g, inv);
         }
         float direct = dot3(g, mk3(-1.f, -1.f, 1.f)) * DIRECT_FACTOR;   /* :183 */
@@ -727,8 +765,16 @@ unsigned long long vvo_render(const vvo_volume *v, const float tf[1024], int W, 
 #ifdef _OPENMP
     #pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+:executed)
 #endif
-    for (long b = 0; b < (long)nby * nbx; b++)
+    for (long b = 0; b < (long)nby * nbx; b++) {
+#if VVO_MODEL == 2
+        const unsigned csr = _mm_getcsr();
+        _mm_setcsr(csr | 0x8040u);               /* FTZ + DAZ, as -use_fast_math's -ftz=true */
+#endif
         executed += render_block(&F, (int)(b % nbx), (int)(b / nbx), rgba);
+#if VVO_MODEL == 2
+        _mm_setcsr(csr);
+#endif
+    }
     return executed;
 }
 

@@ -23,10 +23,28 @@ class vvo_volume(C.Structure):
 
 _oracle = None
 _ref = None
+_models = {}
+MODELS = ("pins", "fmad", "fast", "textrunc")     # oracle/vvo.c VVO_MODEL; "pins" is the oracle proper
 
 
-def oracle() -> C.CDLL:
+def oracle(model: str = "pins") -> C.CDLL:
+    """The oracle library; model != "pins" loads the same restatement built under another arithmetic model
+    (oracle/Makefile `models`: measurement only, never a parity target)."""
     global _oracle
+    if model != "pins":
+        if model not in _models:
+            so = os.path.join(REPO, "oracle", "_build", f"libvvoracle_{model}.so")
+            if not os.path.exists(so):
+                subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "models"], stdout=subprocess.DEVNULL)
+            lib = C.CDLL(so)
+            lib.vvo_render.argtypes = [C.POINTER(vvo_volume), C.c_void_p, C.c_int, C.c_int, C.POINTER(vv.slice_params),
+                                       C.POINTER(vv.camera_params), C.POINTER(vv.shading_params),
+                                       C.POINTER(vv.vv_ray_source), C.POINTER(vv.vv_render_options), C.c_void_p, C.c_int]
+            lib.vvo_render.restype = C.c_ulonglong
+            lib.vvo_model.restype = C.c_char_p
+            assert lib.vvo_model().decode() == model
+            _models[model] = lib
+        return _models[model]
     if _oracle is None:
         if not os.path.exists(ORACLE_SO):
             subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle")], stdout=subprocess.DEVNULL)
@@ -144,7 +162,7 @@ def first_pass(cam: vv.Camera, W, H):
 
 
 def render(vol, tf, width, height, cam: vv.Camera, *, slice=None, phong=False, rays=None, options=None,
-           out=None, fill=0, threads=0):
+           out=None, fill=0, threads=0, model="pins"):
     """Returns (rgba [H,W,4] uint8, executed_samples)."""
     v = _vol(vol)
     tf = np.ascontiguousarray(tf, np.float32).reshape(1024)
@@ -154,7 +172,7 @@ def render(vol, tf, width, height, cam: vv.Camera, *, slice=None, phong=False, r
     cp = cam.params(width, height)
     sh = vv.shading_params(-1, phong)
     rs = rays if rays is not None else vv.analytic_rays(cam)
-    n = oracle().vvo_render(C.byref(v), tf.ctypes.data, width, height, C.byref(sp), C.byref(cp), C.byref(sh),
+    n = oracle(model).vvo_render(C.byref(v), tf.ctypes.data, width, height, C.byref(sp), C.byref(cp), C.byref(sh),
                             C.byref(rs), C.byref(options) if options is not None else None,
                             out.ctypes.data, threads)
     return out, int(n)

@@ -108,3 +108,36 @@ def test_async_double_buffered_gather(world, n_frames):
     for k, f in enumerate(done):
         want = np.array([[(k * 37 + y) % 251] * 4 for y in range(H)], np.uint8)[:, None, :].repeat(W, axis=1)
         assert np.array_equal(f, want), k
+
+
+def test_native_gather_band_bookkeeping():
+    """vv_mgpu_band_rows (host arithmetic of the native RCCL gather, include/volviz_mgpu.h): for every band the rank and
+    the pixel rows it sends are exactly the rows vv_render's shard predicate lets that rank write -- rows of the slab-row
+    range, never row H-1 (kernel.cu:297-298) -- so the landing-frame copy can never touch a pixel the rank did not render."""
+    import ctypes as C
+    repo = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    lib = C.CDLL(os.path.join(repo, "volume-viz_amd", "lib", "libvolviz_mgpu.so"))
+    f = lib.vv_mgpu_band_rows
+    f.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)] * 3
+    for H in (2, 14, 15, 29, 43, 56, 57, 113, 300, 1080, 2160):
+        nby = H // 14 + (1 if H % 14 else 0)
+        for n in (1, 2, 3, 4, 8):
+            for rb, re in ((0, 0), (0, nby), (1, max(1, nby - 1)), (nby // 2, nby)):
+                if rb > re or re > nby:
+                    continue
+                lo, hi = (0, nby) if (rb, re) == (0, 0) else (rb, re)
+                want = {r: set() for r in range(n)}
+                for y in range(H - 1):
+                    s = y // 14
+                    if lo <= s < hi:
+                        want[(s // 4) % n].add(y)
+                got = {r: set() for r in range(n)}
+                nbands = (H + 55) // 56
+                for b in range(nbands):
+                    rk, ya, yb = C.c_int(), C.c_int(), C.c_int()
+                    assert f(H, n, rb, re, b, C.byref(rk), C.byref(ya), C.byref(yb)) == 0
+                    assert 0 <= ya.value <= yb.value <= H - 1 and rk.value == b % n
+                    got[rk.value] |= set(range(ya.value, yb.value))
+                assert got == want, (H, n, rb, re)
+                rk, ya, yb = C.c_int(), C.c_int(), C.c_int()
+                assert f(H, n, rb, re, nbands, C.byref(rk), C.byref(ya), C.byref(yb)) != 0      # band out of range

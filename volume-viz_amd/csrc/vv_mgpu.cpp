@@ -159,7 +159,7 @@ int vv_mgpu_band_rows(int H, int n, int slab_row_begin, int slab_row_end, int ba
     if (ya < rb * kSlab) ya = rb * kSlab;
     if (yb > re * kSlab) yb = re * kSlab;
     if (yb > H - 1) yb = H - 1;                    // row H-1 is never written
-    if (yb < ya) yb = ya;
+    if (ya > yb) ya = yb;                         // empty: the band lies outside the slab-row range
     *rank = band % n; *y_begin = ya; *y_end = yb;
     return VV_OK;
 }

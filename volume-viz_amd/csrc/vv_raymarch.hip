@@ -383,6 +383,14 @@ __global__ __launch_bounds__(256) void march_skew_kernel(FrameParams P, VolumeVi
         // `while (dist < upper)` fails) or it terminated for good
         const bool pending = active && !(lastc && i > n) && !(P.ert_true && ert);
         if (!__any(pending)) break;
+        // No lane has a sample left in its open chunk (the wave's rays have all terminated early and composite one sample
+        // per chunk, pin 4; or lanes idle before their first chunk): jump to the first lane's next chunk boundary instead of
+        // stepping -- and gathering -- through the idle slots.  (Positions are recomputed at every boundary, :249.)
+        if (!__any(i <= n && !stop)) {
+            int d = pending ? 31 - i : 64;       // (finished lanes no longer open chunks: their i may run on)
+            for (int q = 32; q > 0; q >>= 1) d = min(d, __shfl_xor(d, q));
+            i += d;
+        }
         if (INSTR) slots += (unsigned long long)U * 64ull;
         float tx[U], ty[U], tz[U], du[SLICE == SLICE_PLANE ? U : 1];
         int iu[U];
