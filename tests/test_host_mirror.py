@@ -92,3 +92,45 @@ def test_native_multi_gpu_entry_points_on_the_visible_gpus():
     r = subprocess.run([demo, "0", "96", "400", "300"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 differing bytes" in r.stdout, r.stdout
+
+
+def test_paint_loop_symbols():
+    """CPU check: the GLWidget-shaped loop (host/paint_loop.h) is part of the mirror library."""
+    so = os.path.join(REPO, "volume-viz_amd", "lib", "libvolviz_host.so")
+    out = subprocess.check_output(["nm", "-D", "-C", "--defined-only", so]).decode()
+    for name in ("PaintLoop::paintGL()", "PaintLoop::resizeGL(int, int)", "PaintLoop::orbitDrag(int, int)", "PaintLoop::setSliceCanonical(int, float)"):
+        assert name in out, name
+
+
+@pytest.mark.gpu
+def test_paint_loop_matches_oracle(tmp_path):
+    """host/paint_loop.cpp = GLWidget::paintGL / resizeGL (glwidget.cpp:188-391) without Qt and GL: first pass into two
+    widget-sized images, runCuda at a third of the size only when the frame is dirty, render-time value.  bin/paint_loop_demo
+    plays a short session (first paint; a clean repaint; orbit drag + Phong; coronal cross-section + zoom); every frame it
+    showed equals the oracle's march over the first-pass images it used, and those equal the oracle's first pass."""
+    demo = os.path.join(REPO, "volume-viz_amd", "bin", "paint_loop_demo")
+    ww, wh = 510, 384
+    r = subprocess.run([demo, str(tmp_path), str(ww), str(wh)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "3 of 4 paints marched" in r.stdout, r.stdout
+    W, H = ww // 3, wh // 3
+    vol = O.draw_default_brain(64, 64, 64)
+    tf = O.transfer_preset(vv.TF_ENGINE)
+    pos0 = np.array([0.0, 0.0, -4.0], np.float32)
+    pos1, look1 = vv.camera_orbit_drag(pos0, 37, -21)
+    pos2 = vv.camera_zoom(pos1, look1, 60)
+    pt, nrm = vv.cut_plane_canonical(vv.CORONAL, 0.1)
+    sp2 = vv.cut_plane_to_slice_params(vv.SLICE_PLANE_CUT, pt, nrm, False)
+    sessions = [(pos0, -pos0, None, False), (pos1, look1, None, True), (pos2, look1, sp2, True)]
+    lit = 0
+    for k, (pos, look, sp, phong) in enumerate(sessions):
+        front = np.fromfile(tmp_path / f"front{k}.rgba", np.uint8).reshape(wh, ww, 4)
+        back = np.fromfile(tmp_path / f"back{k}.rgba", np.uint8).reshape(wh, ww, 4)
+        cam_w = vv.Camera(origin=tuple(float(v) for v in pos), look_at=tuple(float(a + b) for a, b in zip(pos, look)))
+        of, ob = O.first_pass(cam_w, ww, wh)
+        assert np.array_equal(front, of) and np.array_equal(back, ob), f"first pass {k}"
+        got = np.fromfile(tmp_path / f"frame{k}.rgba", np.uint8).reshape(H, W, 4)
+        want, _ = O.render(vol, tf, W, H, cam_w, slice=sp, phong=phong, rays=vv.image_rays(front, back), fill=0)
+        assert np.array_equal(got, want), f"frame {k}"
+        lit += int((got[..., 3] > 0).sum())
+    assert lit > 3 * W * H // 20

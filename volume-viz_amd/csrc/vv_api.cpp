@@ -246,6 +246,7 @@ int vv_prepare_layouts(vv_context *c, int which, void *stream)
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = pick_stream(c, stream);
     int built = 0;
+    if (which & VV_LAYOUT_BRICKED) c->bricks_failed = false;       // an explicit request retries after an earlier shortage of HBM
     if ((which & VV_LAYOUT_BRICKED) && ensure_bricks(c, st)) built |= VV_LAYOUT_BRICKED;
     if ((which & VV_LAYOUT_ZPAIR) && ensure_zpair(c, st)) built |= VV_LAYOUT_ZPAIR;
     return built;
@@ -294,9 +295,10 @@ int vv_reread_env(vv_context *c)
 
 int vv_debug_sweep_trace(vv_context *c, unsigned long long *out, int max_blocks)
 {
-    if (!c || !out || !c->d_trace) return VV_ERR_INVALID;
+    if (!c || !out || !c->d_trace || max_blocks < 0) return VV_ERR_INVALID;
     const int n = c->trace_blocks < max_blocks ? c->trace_blocks : max_blocks;
-    if (hipDeviceSynchronize() != hipSuccess) return VV_ERR_DEVICE;
+    if (hipSetDevice(c->device) != hipSuccess) return VV_ERR_DEVICE;
+    if (c->timed && hipEventSynchronize(c->ev1) != hipSuccess) return VV_ERR_DEVICE;      // the frame that wrote the trace
     if (hipMemcpy(out, c->d_trace, 64ull * n, hipMemcpyDeviceToHost) != hipSuccess) return VV_ERR_DEVICE;
     return n;
 }
