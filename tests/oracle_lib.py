@@ -154,9 +154,9 @@ def ray_endpoints(rs, cam: vv.Camera, W, H, x, y):
     return f, b
 
 
-def first_pass(cam: vv.Camera, W, H):
+def first_pass(cam: vv.Camera, W, H, rays=None):
     front = np.zeros((H, W, 4), np.uint8); back = np.zeros((H, W, 4), np.uint8)
-    rs = vv.analytic_rays(cam); cp = cam.params(W, H)
+    rs = rays if rays is not None else vv.analytic_rays(cam); cp = cam.params(W, H)
     oracle().vvo_first_pass(C.byref(rs), C.byref(cp), W, H, front.ctypes.data, back.ctypes.data)
     return front, back
 

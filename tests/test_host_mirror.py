@@ -126,8 +126,10 @@ def test_paint_loop_matches_oracle(tmp_path):
     for k, (pos, look, sp, phong) in enumerate(sessions):
         front = np.fromfile(tmp_path / f"front{k}.rgba", np.uint8).reshape(wh, ww, 4)
         back = np.fromfile(tmp_path / f"back{k}.rgba", np.uint8).reshape(wh, ww, 4)
-        cam_w = vv.Camera(origin=tuple(float(v) for v in pos), look_at=tuple(float(a + b) for a, b in zip(pos, look)))
-        of, ob = O.first_pass(cam_w, ww, wh)
+        cam_w = vv.Camera(origin=tuple(float(v) for v in pos))
+        rs = vv.analytic_rays(cam_w, aspect=ww / wh)
+        rs.look[:] = [float(v) for v in look]                  # (after the zoom the view direction is no longer -position)
+        of, ob = O.first_pass(cam_w, ww, wh, rays=rs)
         assert np.array_equal(front, of) and np.array_equal(back, ob), f"first pass {k}"
         got = np.fromfile(tmp_path / f"frame{k}.rgba", np.uint8).reshape(H, W, 4)
         want, _ = O.render(vol, tf, W, H, cam_w, slice=sp, phong=phong, rays=vv.image_rays(front, back), fill=0)

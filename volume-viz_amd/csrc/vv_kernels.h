@@ -23,6 +23,7 @@ struct SweepArgs {
     int ntx, nty;          // tile grid
     int y0, rows_per_band, band_stride_px;   // pixel row of tile row t: y0 + (t / rows_per_band) * band_stride_px + (t % rows_per_band) * 2 wy
     int group;             // slices per loader group (one footprint, one allocation, one confirmation)
+    int wmax;              // widest slice window (in slices) a consumer wave may need and still use the ring
     int pxc, ry, ring;     // LDS image of a slice: ry rows of pxc 128-byte cells; `ring` slots (power of two)
     int slot_bytes;        // pxc * 128 * ry
     int lds_bytes;         // dynamic LDS of the launch

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
     const bool in_frame = x <= xmax && y <= ymax && row_owned(P, y);
 
     float res_r = 0.f, res_g = 0.f, res_b = 0.f, res_a = 0.f;
-    unsigned long long executed = 0, slots = 0, misses = 0, stalls = 0;
+    unsigned long long executed = 0, slots = 0, misses = 0;
     bool write_zero = false;
     Ray r;
     bool alive = false;
@@ -368,173 +368,216 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
     __syncthreads();
     const int kmin = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmin));
 
-    float dist = r.dist0;
-    int i = 0, n = 0, chunks = 0;             // next sample of the open chunk (0: the lane has to open a chunk), samples in it
-    float px = 0.f, py = 0.f, pz = 0.f;
-    bool ert = false;
-    int tail = 0;                             // wave-uniform: the wave has left the ring (its live rays have all terminated early)
-    int pw = 0;                               // published progress of this wave
-    int kl = kmin;                            // slices k < kl have landed
-    int stall_run = 0, n_iter = 0, n_stall = 0;
-    // the lane's candidate sample (valid while `cand`): position, texture coordinates, weights, voxel / slice indices
-    bool cand = false, inb = false;
-    float qx = 0.f, qy = 0.f, qz = 0.f, wx = 0.f, wy = 0.f, wz = 0.f, ctx_ = 0.f, cty_ = 0.f, ctz_ = 0.f;
-    uint32_t ix = 0;
-    int ir = 0, k0 = 0, need = 0;
-    const int needoff = S.sgn > 0 ? 1 : 0;
-    unsigned long long t_stall = 0, t_c0 = __builtin_readcyclecounter(), t_s = 0;
-    const unsigned long long t_loop0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const unsigned long long t_r0 = INSTR ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
-
-    for (;;) {
-        if (INSTR) t_s = __builtin_readcyclecounter();
-        // ---- open the next 30-sample chunk (kernel.cu:248-257): its sample count by the reference's own predicate ----
-        if (any_(alive && i == 0)) {
-            if (alive && i == 0) {
-#pragma clang fp contract(off)
-                if (!(dist < r.upper) || chunks >= P.max_chunks) alive = false;
-                else {
-                    n = chunk_count(dist, r.upper, r.sstep);
-                    if (ert) n = min(n, 1);                              // DESIGN.md pin 4: later chunks composite one sample
-                    ++chunks;
-                    if (n == 0) dist += r.sstep * kChunkSteps;           // the inner loop breaks at i == 1 (kernel.cu:255-257)
-                    else { px = r.origin.x + r.dir.x * dist; py = r.origin.y + r.dir.y * dist; pz = r.origin.z + r.dir.z * dist; i = 1; }
-                }
-            }
+    // ---------------------------------------------------------------------------------------------------------------
+    // Per-wave skewed lock step (round 3; round 2's consumer paced every LANE by itself and spent 386 VALU instructions
+    // per step on that).  As in march_skew_kernel (vv_raymarch.hip) lane L takes its sample s = tau - o_L at wave step
+    // tau, with o_L chosen so that all lanes of the wave sit within about one sample spacing of a common position along
+    // the sweep axis; every lane still executes exactly the reference's operations for its ray.  The wave's slice window
+    // of a trip -- [floor(min_L kc_L), floor(max_L kc_L) + 1] in sweep positions -- is then a few slices wide and is
+    // tracked with scalars: kc_L(tau) = A_L + tau * D_L per lane (positions are affine in the sample number), the wave
+    // extremes are re-anchored by two wave reductions every kAnchor steps and run on the extreme slopes in between.
+    // One scalar test per trip against `landed`, one scalar release through progress[wave]; no per-lane waiting.
+    // A wave whose window would not fit the ring (lanes entering through different faces at the cube's silhouette) or
+    // whose live rays have all terminated early takes its samples by direct gathers instead (`tail`).
+    // ---------------------------------------------------------------------------------------------------------------
+    constexpr int U = 2;                      // samples per trip (LDS latency is short: depth buys nothing, window costs ring)
+    constexpr int kAnchor = 16;
+    constexpr float kWinMargin = 0.125f;      // slices; the affine model is exact to ~1e-3
+    const float fns = (float)ns;
+    float kA = 0.f, kD = 1.f;                 // kc_L(tau) = kA + tau * kD
+    int o = 0;
+    float Dmin = 1.f, Dmax = 1.f;
+    {
+        const float isc = MAJOR == 2 ? P.inv_scale[2] : P.inv_scale[1];
+        const float p1 = MAJOR == 2 ? r.origin.z + r.sdir.z : r.origin.y + r.sdir.y;              // first sample (dist0 = 0: no cutting plane here)
+        const float z1 = __builtin_fmaf(p1 - 0.5f, isc, 0.5f) * fns - 0.5f;                          // its slice coordinate
+        const float dz = (MAJOR == 2 ? r.sdir.z : r.sdir.y) * isc * fns;
+        const float kc1 = S.sgn > 0 ? z1 : fns - z1;
+        kD = fabsf(dz);
+        const bool ok = alive && kD > 1e-6f && kc1 == kc1;
+        int m = __float_as_int(ok ? fmaxf(kc1 + 1024.f, 0.f) : INFINITY);                            // (+1024: ordered as integers also below 0)
+        m = wave_min_fast(m);
+        const float cref = __int_as_float(m) - 1024.f;
+        if (ok) {
+            const float q = rintf((kc1 - cref) / kD);
+            o = q >= 0.f ? (q < 30.f ? (int)q : 30) : 0;
         }
-        if (!any_(alive)) break;
-        if (!tail && !any_(alive && !ert)) {
+        kA = kc1 - (float)(o + 1) * kD;
+        // (positive floats order like their bit patterns: minimum / maximum by the integer reductions)
+        Dmin = __int_as_float(wave_min_fast(ok ? __float_as_int(kD) : 0x7f800000));
+        Dmax = __int_as_float(-wave_min_fast(ok ? -__float_as_int(kD) : 0));
+        if (!(Dmin <= Dmax)) { Dmin = 1.f; Dmax = 1.f; }                      // no lane of this wave marches
+    }
+
+    float dist = r.dist0;
+    bool ert = false, stop = false, active = alive, lastc = false;
+    int i = 31 - o;                           // next sample of the lane's chunk; 31 = open the next chunk now
+    int n = 0, chunks = 0;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    int tail = 0;                             // wave-uniform: the wave takes its samples by direct gathers (it has left the ring)
+    int pw = 0;                               // published progress of this wave
+    int tau = 1;                              // wave step of the trip's first slot
+    int tau0 = -1000000;                      // step of the last re-anchoring
+    float lo0 = 0.f, hi0 = 0.f;               // wave extremes of kc at tau0
+    const int kmaxT = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmax));
+    const int tmax = P.max_chunks * 30 + 30 + U;
+    int stall_run = 0, n_iter = 0, n_stall = 0;
+    const unsigned long long t_loop0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+
+    for (int t = 0; t < tmax; t += U) {
+        const bool pending = active && !(lastc && i > n) && !(P.ert_true && ert);
+        if (!__any(pending)) break;
+        // every lane idle until its next chunk boundary: jump there (march_skew_kernel)
+        if (!__any(i <= n && !stop)) {
+            int d = pending ? 31 - i : 64;
+            d = wave_min_fast(d);
+            i += d; tau += d;
+        }
+        // all live rays terminated early: the remaining samples are one per 30-sample chunk -- not worth the stream
+        if (!tail && !__any(pending && !ert)) {
             tail = 1;
             if (lane == 0) lds_store_i(&ctl->progress[wave], kInf);
         }
+        if (!tail) {
+            // ---- the wave's slice window for this trip ----
+            if (tau - tau0 >= kAnchor) {
+                const float kc = fminf(fmaxf(kA + (float)tau * kD, (float)kmin), (float)kmaxT);     // pending lanes; >= 0
+                const int mn = wave_min_fast(pending ? __float_as_int(kc) : 0x7f800000);
+                const int mx = wave_min_fast(pending ? -__float_as_int(kc) : 0);
+                lo0 = __int_as_float(mn); hi0 = __int_as_float(-mx); tau0 = tau;
+                if (!(hi0 - lo0 + (float)kAnchor * (Dmax - Dmin) + (float)U * Dmax + 2.f * kWinMargin + 3.f <= (float)S.wmax)) {
+                    // the window does not fit the ring: this wave marches on direct gathers from here on
+                    tail = 1;
+                    if (lane == 0) lds_store_i(&ctl->progress[wave], kInf);
+                }
+            }
+        }
         tail = __builtin_amdgcn_readfirstlane(tail);
+        if (!tail) {
+            const float dt0 = (float)(tau - tau0);
+            const float lo_f = lo0 + dt0 * Dmin - kWinMargin, hi_f = hi0 + (dt0 + (float)(U - 1)) * Dmax + kWinMargin;
+            const int need_lo = __builtin_amdgcn_readfirstlane(max((int)floorf(lo_f), kmin));
+            const int need_hi = __builtin_amdgcn_readfirstlane(min((int)floorf(hi_f) + 1, kmaxT));
+            if (need_lo > pw) { pw = need_lo; if (lane == 0) lds_store_i(&ctl->progress[wave], pw); }
+            for (;;) {
+                const i4v l4 = lds_load_i4(ctl->landed);
+                const int kl = __builtin_amdgcn_readfirstlane(min(min(l4.x, l4.y), min(l4.z, l4.w)));
+                if (kl > need_hi) break;
+                if (INSTR) ++n_stall;
+                __builtin_amdgcn_s_sleep(1);
+                if (++stall_run > (1 << 21)) {               // watchdog: a wrong pixel beats a hung GPU
+                    if (lane == 0) { lds_store_i(&ctl->err, 3); lds_store_i(&ctl->progress[wave], kInf); }
+                    tail = 1;
+                    break;
+                }
+            }
+            stall_run = 0;
+            asm volatile("" ::: "memory");        // the flag is read before any slice data of this step
+        }
+        ++n_iter;
+        if (INSTR) slots += (unsigned long long)U * 64ull;
 
-        // ---- candidate: sample i of the open chunk (kernel.cu:136-141).  Computed once per sample: while a lane waits for
-        //      its slices its candidate stays valid, so an iteration in which nothing changed costs a dozen instructions.
-        //      (Recomputing for lanes whose candidate is still valid gives the same values: no selects.) ----
-        const bool open = alive && i != 0;
-        if (any_(open && !cand)) {
-            qx = px + r.sdir.x; qy = py + r.sdir.y; qz = pz + r.sdir.z;
-            const float tx = __builtin_fmaf(qx - 0.5f, P.inv_scale[0], 0.5f);
-            const float ty = __builtin_fmaf(qy - 0.5f, P.inv_scale[1], 0.5f);
-            const float tz = __builtin_fmaf(qz - 0.5f, P.inv_scale[2], 0.5f);
-            uint32_t iy, iz;
-            wx = axis_coord<TEX8>(tx, (float)V.nx, (float)(V.nx - 1), ix);
-            wy = axis_coord<TEX8>(ty, (float)V.ny, (float)(V.ny - 1), iy);
-            wz = axis_coord<TEX8>(tz, (float)V.nz, (float)(V.nz - 1), iz);
-            inb = bounds_check(tx, ty, tz);
-            ctx_ = tx; cty_ = ty; ctz_ = tz;
-            const int is = (int)(MAJOR == 2 ? iz : iy);
-            ir = (int)(MAJOR == 2 ? iy : iz);
-            k0 = (is ^ kxor) + kxadd;                    // position of slice `is`; slice is + 1 sits at k0 + kmul
-            need = k0 + needoff;                         // the later of the two
-            cand = open;
-            // ---- release slices no lane of this wave will read again: a ray's positions only grow, so the earlier slice of
-            //      its candidate bounds everything it will still read.  Done before the wave may stall: a wave that waits
-            //      for slices far ahead must not hold the ring back (its published progress gates the loaders) ----
-            if (!tail) {
-                const int fr = need - 1;
-                if (!any_(alive && fr <= pw)) {
-                    const int m = wave_min_fast(alive ? fr : kInf);
-                    if (m < kInf && m > pw) {
-                        pw = m;
-                        if (lane == 0) lds_store_i(&ctl->progress[wave], pw);
+        uint32_t idx[U];
+        int iu[U];
+        bool lv[U];
+        float ttx[U], tty[U], ttz[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // ---- chunk boundary of this lane: close the old chunk (:277), open the next (:248-249) ----
+            if (__any(i == 31)) {
+                if (i == 31) {
+#pragma clang fp contract(off)
+                    if (chunks > 0) { dist += r.sstep * kChunkSteps; if (P.ert_true && ert) r.upper = -1.f; }
+                    i = 1; n = 0;
+                    if (active) {
+                        if (chunks >= P.max_chunks) active = false;
+                        else {
+                            n = chunk_count(dist, r.upper, r.sstep);
+                            lastc = n < 30;
+                            if (ert) n = min(n, 1);                          // DESIGN.md pin 4 (tables here have opacities in [0, 1])
+                            px = r.origin.x + r.dir.x * dist; py = r.origin.y + r.dir.y * dist; pz = r.origin.z + r.dir.z * dist;
+                            ++chunks;
+                            if (n == 0) active = false;
+                        }
                     }
                 }
             }
-        }
-        if (!tail) { const i4v l4 = lds_load_i4(ctl->landed); kl = min(min(l4.x, l4.y), min(l4.z, l4.w)); }
-        asm volatile("" ::: "memory");        // the flag is read before any slice data of this step
-        const bool take = open && (tail != 0 || need < kl);
-        if (!any_(take)) {
-            if (any_(alive && i == 0)) continue;         // an empty chunk: open the next one
-            // nothing to do until the loaders catch up
-            if (INSTR) ++stalls;
-            ++n_stall;
-            __builtin_amdgcn_s_sleep(1);
-            if (INSTR) t_stall += __builtin_readcyclecounter() - t_s;
-            if (++stall_run > (1 << 21)) {               // watchdog: a wrong pixel beats a hung GPU
-#ifdef VV_SWEEP_DEBUG
-                {
-                    const int mn = wave_min_fast(open ? need : kInf);
-                    if (lane == 0) printf("watchdog tile (%d,%d) wave %d: kl %d min need %d pw %d kmin %d kmax %d\n", tcol, trow, wave, kl, mn, pw, kmin, lds_load_i(&ctl->kmax));
+            px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;                  // :141
+            const float tx = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
+            const float ty = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
+            const float tz = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
+            ttx[u] = tx; tty[u] = ty; ttz[u] = tz;
+            iu[u] = i; lv[u] = i <= n;
+            ++i;
+            if (!tail) {
+                uint32_t ix, iy, iz;
+                const float wx = axis_coord<TEX8>(tx, (float)V.nx, (float)(V.nx - 1), ix);
+                const float wy = axis_coord<TEX8>(ty, (float)V.ny, (float)(V.ny - 1), iy);
+                const float wz = axis_coord<TEX8>(tz, (float)V.nz, (float)(V.nz - 1), iz);
+                const bool inb = bounds_check(tx, ty, tz);
+                const int is = (int)(MAJOR == 2 ? iz : iy), ir = (int)(MAJOR == 2 ? iy : iz);
+                const int k0 = (is ^ kxor) + kxadd;              // position of slice `is`; slice is + 1 sits at k0 + kmul
+                const i2v T0 = lds_load_i2(&ctl->tab[k0 & (kTab - 1)]), T1 = lds_load_i2(&ctl->tab[(k0 + kmul) & (kTab - 1)]);
+                const int x4 = (int)(ix << 2);
+                const char *p0 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)T0.y) + (T0.x + x4));
+                const char *p1 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)T1.y) + (T1.x + x4));
+                float2u c00, c10, c01, c11;
+                lds_pairs(p0, p0 + T0.y, p1, p1 + T1.y, c00, c10, c01, c11);
+                // MAJOR == 2: rows are y, slices z.  MAJOR == 1: rows are z, slices y -- the lerp order stays x, y, z
+                const float2u a_ = c00, b_ = MAJOR == 2 ? c10 : c01, c_ = MAJOR == 2 ? c01 : c10, d_ = c11;
+                const float e00 = __builtin_fmaf(wx, a_.y - a_.x, a_.x);
+                const float e10 = __builtin_fmaf(wx, b_.y - b_.x, b_.x);
+                const float e01 = __builtin_fmaf(wx, c_.y - c_.x, c_.x);
+                const float e11 = __builtin_fmaf(wx, d_.y - d_.x, d_.x);
+                const float f0 = __builtin_fmaf(wy, e10 - e00, e00);
+                const float f1 = __builtin_fmaf(wy, e11 - e01, e01);
+                const float L = __builtin_fmaf(wz, f1 - f0, f0);
+                uint32_t id = min((uint32_t)(L * 255.0f), 255u);
+                idx[u] = inb ? id : 0u;
+                if (INSTR && lv[u] && inb) {
+                    const int *bx0 = ctl->box[k0 & (kTab - 1)], *bx1 = ctl->box[(k0 + kmul) & (kTab - 1)];
+                    const bool okb = (int)ix >= bx0[0] && (int)ix + 1 <= bx0[1] && ir >= bx0[2] && ir + 1 <= bx0[3] &&
+                                     (int)ix >= bx1[0] && (int)ix + 1 <= bx1[1] && ir >= bx1[2] && ir + 1 <= bx1[3];
+                    // (a sample masked by `stop` / early termination below may lie ahead of the window: only live ones count)
+                    if (!okb && !stop && !(P.ert_true && ert)) ++misses;
                 }
-#endif
-                if (lane == 0) { lds_store_i(&ctl->err, 3); lds_store_i(&ctl->progress[wave], kInf); }
-                alive = false;
+            } else {
+                idx[u] = V.big ? sample_index<VV_VOXEL_F32, TEX8, true>(V, tx, ty, tz) : sample_index<VV_VOXEL_F32, TEX8, false>(V, tx, ty, tz);
             }
-            continue;
         }
-        stall_run = 0; ++n_iter;
-        if (INSTR) slots += 64;
-
-        // ---- eight corners ----
-        uint32_t idx;
-#ifdef VV_SWEEP_DUMMY_CONSUMER
-        // experiment build: consumers take their samples without reading the slices (pipeline rate of the loaders alone)
-        if (true) { idx = (uint32_t)(k0 & 255); } else
-#endif
-        if (!tail) {
-            const i2v T0 = lds_load_i2(&ctl->tab[k0 & (kTab - 1)]), T1 = lds_load_i2(&ctl->tab[(k0 + kmul) & (kTab - 1)]);
-            const int x4 = (int)(ix << 2);
-            const char *p0 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)T0.y) + (T0.x + x4));
-            const char *p1 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)T1.y) + (T1.x + x4));
-            float2u c00, c10, c01, c11;
-            lds_pairs(p0, p0 + T0.y, p1, p1 + T1.y, c00, c10, c01, c11);
-            // MAJOR == 2: rows are y, slices z.  MAJOR == 1: rows are z, slices y -- the lerp order stays x, y, z
-            const float2u a_ = c00, b_ = MAJOR == 2 ? c10 : c01, c_ = MAJOR == 2 ? c01 : c10, d_ = c11;
-            const float e00 = __builtin_fmaf(wx, a_.y - a_.x, a_.x);      // (y, z)
-            const float e10 = __builtin_fmaf(wx, b_.y - b_.x, b_.x);      // (y+1, z)
-            const float e01 = __builtin_fmaf(wx, c_.y - c_.x, c_.x);      // (y, z+1)
-            const float e11 = __builtin_fmaf(wx, d_.y - d_.x, d_.x);
-            const float f0 = __builtin_fmaf(wy, e10 - e00, e00);
-            const float f1 = __builtin_fmaf(wy, e11 - e01, e01);
-            const float L = __builtin_fmaf(wz, f1 - f0, f0);
-            idx = min((uint32_t)(L * 255.0f), 255u);
-            idx = inb ? idx : 0u;
-            if (INSTR && take && inb) {
-                const int *bx0 = ctl->box[k0 & (kTab - 1)], *bx1 = ctl->box[(k0 + kmul) & (kTab - 1)];
-                const bool ok = (int)ix >= bx0[0] && (int)ix + 1 <= bx0[1] && ir >= bx0[2] && ir + 1 <= bx0[3] &&
-                                (int)ix >= bx1[0] && (int)ix + 1 <= bx1[1] && ir >= bx1[2] && ir + 1 <= bx1[3];
-                if (!ok) ++misses;
+        tau += U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (iu[u] == 1) stop = false;                    // the inner loop's break flag is per chunk (:272-274)
+            const bool live = lv[u] && !stop && !(P.ert_true && ert);
+            float cr, cg, cb, ca;
+            ca = lds_tf[768 + idx[u]];
+            cr = lds_tf[idx[u]];
+            if (GRAY) { cg = cb = cr; }
+            else { cg = lds_tf[256 + idx[u]]; cb = lds_tf[512 + idx[u]]; }
+            if (INSTR && live) {
+                executed++;
+                if (bricks && bounds_check(ttx[u], tty[u], ttz[u])) mark_bricks(bricks, V, ttx[u], tty[u], ttz[u]);
             }
-        } else {
-            idx = V.big ? sample_index<VV_VOXEL_F32, TEX8, true>(V, ctx_, cty_, ctz_) : sample_index<VV_VOXEL_F32, TEX8, false>(V, ctx_, cty_, ctz_);
-        }
-        float cr, cg, cb, ca;
-        ca = lds_tf[768 + idx];
-        cr = lds_tf[idx];
-        if (GRAY) { cg = cb = cr; }
-        else { cg = lds_tf[256 + idx]; cb = lds_tf[512 + idx]; }
-        if (INSTR && take) {
-            executed++;
-            if (bricks && inb) mark_bricks(bricks, V, ctx_, cty_, ctz_);
-        }
-        {
-            // :268-270 + blend :107-118, predicated (the table is finite)
+            {
+                // :268-270 + blend :107-118, predicated (the table is finite)
 #pragma clang fp contract(off)
-            const float bf = (take && ca > kEps) ? ca * (1.f - res_a) : 0.f;
-            res_r = res_r + cr * bf;
-            if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
-            res_a = res_a + bf;
-        }
-        const bool hit = take && res_a > P.ert_thr;                      // :272-274
-        ert = ert || hit;
-        if (take) { px = qx; py = qy; pz = qz; ++i; cand = false; }
-        // the chunk ends after its last sample, or -- the ray terminating early -- after this one
-        if (take && (i > n || hit)) {
-#pragma clang fp contract(off)
-            dist += r.sstep * kChunkSteps;                               // :277
-            i = 0;
-            if (P.ert_true && ert) alive = false;
+                const float bf = (live && ca > kEps) ? ca * (1.f - res_a) : 0.f;
+                res_r = res_r + cr * bf;
+                if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
+                res_a = res_a + bf;
+            }
+            const bool hit = live && res_a > P.ert_thr;                      // :272-274
+            stop = stop || hit;
+            ert = ert || hit;
         }
     }
     if (!tail && lane == 0) lds_store_i(&ctl->progress[wave], kInf);
     if (S.trace && wave == 0 && lane == 0) {
-        unsigned long long *t = S.trace + 8ull * blockIdx.x;
-        t[0] = t_blk0; t[1] = t_loop0; t[2] = __builtin_amdgcn_s_memrealtime();
-        t[3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63508);
-        t[4] = ((unsigned long long)trow << 32) | (unsigned)tcol; t[5] = ((unsigned long long)(unsigned)lds_load_i(&ctl->kmax) << 32) | (unsigned)kmin; t[6] = ((unsigned long long)(unsigned)n_stall << 32) | (unsigned)n_iter; t[7] = 1;
+        unsigned long long *tr = S.trace + 8ull * blockIdx.x;
+        tr[0] = t_blk0; tr[1] = t_loop0; tr[2] = __builtin_amdgcn_s_memrealtime();
+        tr[3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63508);
+        tr[4] = ((unsigned long long)trow << 32) | (unsigned)tcol; tr[5] = ((unsigned long long)(unsigned)kmaxT << 32) | (unsigned)kmin; tr[6] = ((unsigned long long)(unsigned)n_stall << 32) | (unsigned)n_iter; tr[7] = 1;
     }
 
     if (in_frame) {
@@ -546,8 +589,8 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         if (lane == 0 && executed) atomicAdd(counter, executed);
         if (lane == 0 && slots) atomicAdd(counter + 1, slots);
         if (lane == 0 && misses) atomicAdd(counter + 4, misses);
-        if (lane == 0 && stalls) atomicAdd(counter + 6, stalls);
-        if (lane == 0) { atomicAdd(counter + 13, __builtin_readcyclecounter() - t_c0); atomicAdd(counter + 14, t_stall); atomicAdd(counter + 15, __builtin_amdgcn_s_memrealtime() - t_r0); }
+        if (lane == 0 && n_stall) atomicAdd(counter + 6, (unsigned long long)n_stall);
+        if (lane == 0 && tail) atomicAdd(counter + 13, 1ull);                                     // waves that finished on direct gathers
         if (lane == 0 && wave == 0) { const int e = lds_load_i(&ctl->err); if (e) atomicAdd(counter + 7, 1ull << (16 * (e - 1))); }   // four 16-bit counts: codes 1..4
     }
 }
@@ -712,7 +755,7 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
         S.ry = std::min(S.ry, nr + 1);
         S.slot_bytes = S.pxc * 128 * S.ry;                               // the largest image of a slice
         S.ring = (kPages * kPage) / S.slot_bytes;                        // slices of that size the ring holds (it holds more of the smaller ones)
-        if (S.pxc <= 8 && S.ry <= kMaxChunks && S.ring >= 5) break;       // (>= 3 groups of one slice, see below, with room to spare)
+        if (S.pxc <= 8 && S.ry <= kMaxChunks && S.ring >= 12) break;      // a consumer wave's window (~8-10 slices) + two groups must fit
         // footprint too large for the LDS (sparse pixels): smaller tiles, else no sweep
         if (verbose) fprintf(stderr, "sweep: tile %dx%d waves needs pxc %d ry %d ring %d\n", S.wx, S.wy, S.pxc, S.ry, S.ring);
         if (forced) VV_NO("forced tile shape does not fit");
@@ -727,6 +770,11 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
         if (gmax < 1) VV_NO("three groups do not fit the ring");
         S.group = std::min(S.group, gmax);
         if (S.group * S.ry > 62) S.group = std::max(1, 62 / S.ry);             // a group's copies must fit the 6-bit vmcnt
+        // Widest slice window a consumer wave may hold (in slices of the largest size): the ring must also hold the group being
+        // landed, and pages come free only group-wise (up to group - 1 released slices stay resident)
+        while (S.group > 1 && S.ring - 2 * S.group < 9) --S.group;
+        S.wmax = S.ring - 2 * S.group;
+        if (S.wmax < 6) VV_NO("the ring is too small for a wave's slice window");
     }
     S.lds_bytes = kRingOff + kPages * kPage;
     S.order = nullptr; S.n_order = 0; S.trace = nullptr;
