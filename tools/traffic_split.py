@@ -103,6 +103,7 @@ def main():
                           stream=stream, phong=args.phong)
         torch.cuda.synchronize()
         samples = ctx.last_sample_count()
+        cnt = [int(v) for v in ctx.debug_counters()]
         nbricks = int(np.unpackbits(bitmap.cpu().numpy().view(np.uint8)).sum())
         nrows = (rows[1] - rows[0]) * 14 if rows else H
         alg = nbricks * 512 * 4 + 4 * W * nrows + 4096
@@ -123,7 +124,7 @@ def main():
                 ctx.render_device(W, H, cam, frame.data_ptr(), options=o, stream=stream, phong=args.phong)
             torch.cuda.synchronize()
         print(json.dumps({"variant": vi, "name": name, "env": env, "rows": rows, "frames": F, "samples": samples,
-                          "algorithmic_bytes": alg, "ms": None if ms is None else round(ms, 4)}), flush=True)
+                          "algorithmic_bytes": alg, "ms": None if ms is None else round(ms, 4), "counters": cnt}), flush=True)
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips,
 
 struct SlabMap  { int r0, band, band_stride, n_regular; };
 
-// Slab sweep (vv_sweep.hip): a block of nc = wx * wy consumer waves (32 x 2 pixels each) + `nl` loader waves owns a
+// Slab sweep (vv_sweep.hip): a block of nc = wx * wy waves (32 x 2 pixels each; every wave marches AND copies) owns a
 // (32 wx) x (2 wy) pixel tile and walks the volume slice by slice along the sweep axis (y or z; rows along x are
 // contiguous in both cases).
 struct SweepArgs {
@@ -22,7 +22,8 @@ struct SweepArgs {
     int wx, wy, nc, nl;    // consumer waves across / down the tile, their product, loader waves per block
     int ntx, nty;          // tile grid
     int y0, rows_per_band, band_stride_px;   // pixel row of tile row t: y0 + (t / rows_per_band) * band_stride_px + (t % rows_per_band) * 2 wy
-    int group;             // slices per loader group (one footprint, one allocation, one confirmation)
+    int group;             // (1: slices are placed one by one)
+    int ahead;             // trips the copies run ahead of the march
     int wmax;              // widest slice window (in slices) a consumer wave may need and still use the ring
     int pxc, ry, ring;     // LDS image of a slice: ry rows of pxc 128-byte cells; `ring` slots (power of two)
     int slot_bytes;        // pxc * 128 * ry

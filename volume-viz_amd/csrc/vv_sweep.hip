@@ -5,25 +5,27 @@
 // (vv_raymarch.hip), so frames stay bit-identical; what changes is where the eight corners come from.
 //
 // march_kernel gathers them from HBM through the 32 KB L1 (4 wave-wide gathers per sample, 16 cycles of
-// address pipeline each, stalled by every miss).  Here a block of up to 1024 threads owns a wide, short pixel
-// tile (e.g. 96 x 8):
-//   * nc = wx * wy consumer waves, 32 x 2 pixels each, keep one ray per lane in registers;
-//   * nl loader waves walk the slices k = kmin .. kmax the tile's rays cross, in the order the rays
-//     cross them, and copy each slice's footprint of the tile -- the bounding box of the tile's
-//     frustum in that slice, a few hundred voxels wide and two dozen rows high -- HBM -> LDS with
-//     `global_load_lds_dwordx4` (whole 128-byte cells, one image row per wave instruction, no registers)
-//     into a ring of `ring` slice slots;
-//   * a consumer lane takes its next sample as soon as the two slices it interpolates between have
-//     landed (four 8-byte LDS reads), at its own pace: lanes are not in lock step, so a wave needs
-//     no common slab of slices and stalls only when the loaders are behind;
-//   * flags in LDS replace barriers: `loaded` (slices landed, written by the loaders in order) and
-//     `progress[w]` (slices wave w will not read again); a slot is refilled when every wave has let go.
-// Every voxel line of a tile's footprint is read once per tile; neighbouring tiles overlap by the
-// footprint's rim (x: up to one 128-byte cell, y: two rows), which they mostly find in L2.
+// address pipeline each, stalled by every miss) and reads 1.48 x the algorithmic bytes because tiles that share
+// lines do not meet in the L2 in time (profiles/r03_traffic_split.txt).  Here a block of NW waves owns a wide,
+// short pixel tile (e.g. 64 x 8: NW = 8 waves of 32 x 2 pixels, one ray per lane in registers) and walks the
+// slices k = kmin .. kmax its rays cross, in the order they cross them:
+//   * every lane is offset in sample index (block-wide "skewed lock step", as march_skew_kernel does per wave) so
+//     that at block step tau ALL rays of the tile sit within about one sample spacing of a common front along the
+//     sweep axis; the slices a trip of U steps needs are then a window of ~8-10 slices known from scalars
+//     (two block-wide extremes re-anchored every kAnchorTrips trips, run forward on the extreme slopes);
+//   * ALL waves copy: each trip every wave issues its share (rows r = wave mod NW) of the slices the block will
+//     need kAhead trips later, HBM -> LDS with `global_load_lds_dwordx4` (whole 128-byte cells, one image row per
+//     wave instruction, no registers), into a page-granular ring whose layout every wave derives from the same
+//     footprints (no allocation protocol); then waits for ITS OWN rows of the slices this trip needs (a counted
+//     s_waitcnt vmcnt) and meets the others at the one barrier of the trip;
+//   * corners come from LDS (a slice -> image table, four ds_read2_b32 x-pairs), the lerps in the oracle's order.
+// No flags, no polling, no loader / consumer roles (round 2's kernel had all three and lost to them: its flag
+// protocol alone cost 1.2 ms per C3 frame).  Every voxel line of a tile's footprint is read
+// once per tile; neighbouring tiles overlap by the footprint's rim.
 //
-// Reference-mode early ray termination (kernel.cu:272-274: one sample per later 30-sample chunk) would
-// keep the stream running for almost nothing, so a wave whose live rays have all terminated leaves the
-// ring and takes those sparse samples by direct gathers like march_kernel.
+// Reference-mode early ray termination (kernel.cu:272-274: one sample per later 30-sample chunk) would keep the
+// stream running for almost nothing, so once every live ray of the block has terminated -- or if a window ever
+// does not fit the ring -- the block stops copying and each wave finishes on direct gathers like march_kernel.
 #include "vv_device.h"
 #include "vv_kernels.h"
 #include "vv_frustum.h"
@@ -40,7 +42,7 @@ constexpr int kTfBytes = 4096;
 constexpr int kCtlBytes = 2048;
 constexpr int kRingOff = kTfBytes + kCtlBytes;
 constexpr int kLdsMax = 160 * 1024;
-constexpr int kMaxChunks = 60;                 // rows (= LDS-DMA instructions) per slice image: a group's must fit the 6-bit vmcnt
+constexpr int kMaxChunks = 60;                 // rows (= LDS-DMA instructions) per slice image
 constexpr int kPage = 1024;                    // the ring is handed out in pages
 constexpr int kPages = (kLdsMax - kRingOff) / kPage;
 constexpr int kTab = 32;                       // slices the ring can hold at once (table entries)
@@ -48,15 +50,15 @@ constexpr int kTab = 32;                       // slices the ring can hold at on
 typedef int __attribute__((ext_vector_type(4))) i4v;
 typedef int __attribute__((ext_vector_type(2))) i2v;
 struct Ctl {                                   // control block in LDS
-    int landed[4];                             // per loader wave: its rows of the slices k < landed[w] have landed (unused: kInf)
     int kmin, kmax;                            // slice range of the tile (sweep order)
+    int cref;                                  // block reference position (offset float bits): the front at step 1
+    int dmin, dmax;                            // extreme slopes of the block's rays, slices per step (float bits, -bits)
     int err;
-    int alloc;                                 // index of the next group to be given its place in the ring
-    int progress[16];                          // per consumer wave: slices k < progress[w] are released
+    int anc[2][2];                             // double-buffered anchors: {min, -max} of the pending lanes' positions (offset float bits)
+    int pad_[2];
     i2v tab[kTab];                            // per slice k (entry k % kTab): byte address of voxel (x 0, row 0) of its image, row pitch
     int box[kTab][4];                          // per slice: x0, x1, r0, r1 held (instrumented builds check against it)
     int owner[kPages + 2];                     // per ring page: the slice whose image occupies it
-    int dbg[4][8];                             // debug builds: what each loader wave is doing
 };
 static_assert(sizeof(Ctl) <= kCtlBytes, "control block");
 
@@ -123,6 +125,14 @@ __device__ __forceinline__ void wait_vm_n(int n)
     }
 }
 
+constexpr int kU = 2;                          // sample steps per trip (LDS latency is short: a deeper trip only widens the window)
+constexpr int kAnchorTrips = 8;                // the block's extremes are re-anchored every so many trips
+constexpr float kWinMargin = 0.125f;           // slices; the affine position model is exact to ~1e-3
+constexpr float kPosOff = 4096.f;              // positions are offset so that their bit patterns order like integers (they can be < 0)
+
+__device__ __forceinline__ int pos_bits(float kc) { return __float_as_int(fminf(fmaxf(kc, -4000.f), 1.0e6f) + kPosOff); }
+__device__ __forceinline__ float bits_pos(int b) { return __int_as_float(b) - kPosOff; }
+
 // ---------------------------------------------------------------------------------------------
 template <int MAJOR, bool TEX8, bool GRAY, bool INSTR>
 __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V,
@@ -136,8 +146,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
     float *lds_tf = (float *)lds;
     Ctl *ctl = (Ctl *)(lds + kTfBytes);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long t_start = INSTR ? __builtin_readcyclecounter() : 0ull;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = S.nc;
     const unsigned long long t_blk0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // tile of this block.  Raster order dealt to the XCDs by tile row (block L runs on XCD L % 8 under
     // round-robin dispatch: speed only), or the order the host planned.
@@ -165,9 +174,10 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         float4 e = tf[i];
         lds_tf[i] = e.x; lds_tf[256 + i] = e.y; lds_tf[512 + i] = e.z; lds_tf[768 + i] = e.w;
     }
-    if (threadIdx.x < 16) ctl->progress[threadIdx.x] = kInf;
-    if (threadIdx.x == 16) { ctl->kmin = kInf; ctl->kmax = -1; ctl->err = 0; ctl->alloc = 0; }
-    if (threadIdx.x >= 32 && threadIdx.x < 36) ctl->landed[threadIdx.x - 32] = (int)threadIdx.x - 32 < S.nl ? 0 : kInf;
+    if (threadIdx.x == 0) {
+        ctl->kmin = kInf; ctl->kmax = -1; ctl->err = 0; ctl->cref = 0x7f800000; ctl->dmin = 0x7f800000; ctl->dmax = 0;
+        ctl->anc[0][0] = 0x7f800000; ctl->anc[0][1] = 0; ctl->anc[1][0] = 0x7f800000; ctl->anc[1][1] = 0;
+    }
     for (int i = threadIdx.x; i < kPages + 2; i += blockDim.x) ctl->owner[i] = -1;
     __syncthreads();
 
@@ -175,156 +185,9 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
     // slice index s along the sweep axis -> position k in sweep order: s, or ns - s = (s ^ -1) + ns + 1
     const int kmul = S.sgn > 0 ? 1 : -1, kadd = S.sgn > 0 ? 0 : ns;
     const int kxor = S.sgn > 0 ? 0 : -1, kxadd = S.sgn > 0 ? 0 : ns + 1;
+    const float fns = (float)ns;
 
-    if (wave >= S.nc) {
-        // =====================================================================================
-        // loader waves
-        // =====================================================================================
-        const int lw = wave - S.nc;
-        // frustum of the tile from its four corner pixels (pixel centres, ray_endpoints())
-        Frustum F;
-        // the rectangle of the tile's pixels that exist: slopes are ratios of affine functions of the pixel, monotone only
-        // where the denominator keeps its sign, which sweep_axis() checked for the frame's pixels and no further
-        tile_frustum<MAJOR>(P, V, min(x0, P.W - 1), min(y0, P.H - 1), min(x0 + tile_w - 1, P.W - 1), min(y0 + tile_h - 1, P.H - 1), F);
-        FootLin FL;
-        foot_linear(F, S.sgn > 0, FL);
-        // one LDS-DMA piece = one row of the slice's image: lane l copies bytes [16 l, 16 l + 16) of the row
-        // (8 lanes per 128-byte cell; lanes beyond the row's cells are masked)
-        const uint64_t Sr = MAJOR == 2 ? V.row_bytes : V.slice_bytes;       // bytes between rows of the image
-        const uint64_t Ss = MAJOR == 2 ? V.slice_bytes : V.row_bytes;       // bytes between slices
-        __syncthreads();
-        const int kmin = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmin)), kmax = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmax));
-        // ---- loader wave lw: every nl-th group of `group` slices.  The ring is handed out in 1 KiB pages, in slice
-        // order, as a circular first-in-first-out buffer: a group takes ceil(slices * rows * pitch / 1 KiB) pages at
-        // `head`, or at page 0 when they do not fit before the end.  Every loader wave derives the same positions from
-        // the same footprints (it runs the footprints of the other waves' groups too: a few dozen instructions), so
-        // the waves never talk to each other.  Wave w publishes landed[w] = the first slice it has not confirmed yet
-        // (its oldest pending group, else the next group it will issue); everything before the minimum over the
-        // waves has landed.  A page may be overwritten once the group that owns it is released by every consumer wave.
-        // A group shares one footprint (the union over its slices), one allocation and one confirmation: per slice
-        // the loaders' bookkeeping would cost more than the copies themselves. ----
-        const int G = S.group;
-        int gi = 0;                          // index of the next group in the deterministic walk
-        int kn = kmin;                       // its first slice
-        int head = 0, idle = 0;
-        int pk = -1, pn = 0;                 // first slice and instruction count of this wave's pending group (-1: none)
-        bool bail = false;
-        unsigned long long t_issue = 0, t_land = 0, t_pub = 0, t_idle = 0, tt = 0;
-        const unsigned long long t_pro = INSTR ? __builtin_readcyclecounter() - t_start : 0ull;
-        // the first group that is mine
-        auto group_shape = [&](int k0, int &ke, Foot &f) {
-            ke = min(k0 + G - 1, kmax);
-            const int sa = kmul * k0 + kadd, sb = kmul * ke + kadd;
-            const Foot fa = footprint(FL, sa, nx, nr), fb = footprint(FL, sb, nx, nr);
-            f.x0 = __builtin_amdgcn_readfirstlane(min(fa.x0, fb.x0)); f.x1 = __builtin_amdgcn_readfirstlane(max(fa.x1, fb.x1));      // uniform by construction:
-            f.r0 = __builtin_amdgcn_readfirstlane(min(fa.r0, fb.r0)); f.r1 = __builtin_amdgcn_readfirstlane(max(fa.r1, fb.r1));      // scalar loops and branches
-        };
-        if (lane == 0) lds_store_i(&ctl->landed[lw], kmin);
-        for (;;) {
-            if (INSTR) tt = __builtin_readcyclecounter();
-            if (kn > kmax && pk < 0) break;
-            // ---- groups of the other waves: only their place in the ring ----
-            if (kn <= kmax && (gi % S.nl) != lw) {
-                int ke; Foot f;
-                group_shape(kn, ke, f);
-                const int ncell = min((f.x1 >> 5) - (f.x0 >> 5) + 1, S.pxc), nrows = min(f.r1 - f.r0 + 1, S.ry);
-                const int np = ((ke - kn + 1) * nrows * ncell * 128 + kPage - 1) / kPage;
-                head = (head + np <= kPages ? head : 0) + np;
-                kn = ke + 1; ++gi;
-                if (pk < 0 && lane == 0) lds_store_i(&ctl->landed[lw], min(kn, kmax + 1));     // nothing of mine before kn is missing
-                continue;
-            }
-            // ---- my pending group first: it must be confirmed before my next one is issued (one group's instructions
-            //      nearly fill the 6-bit vmcnt) ----
-            if (pk >= 0) {
-                wait_vm<0>();
-                pk = -1;
-                if (lane == 0) lds_store_i(&ctl->landed[lw], min(kn, kmax + 1));               // all my groups before kn have landed
-                if (INSTR) t_land += __builtin_readcyclecounter() - tt;
-                continue;
-            }
-            // ---- my next group: wait for room in the ring, then issue it ----
-            {
-                const int pr = max(__builtin_amdgcn_readlane(row16_min(lds_load_i(&ctl->progress[lane & 15])), 15), kmin);
-                if (pr >= kInf) { bail = true; break; }                 // every consumer wave has left the ring
-                int ke; Foot f;
-                group_shape(kn, ke, f);
-                const int ng = ke - kn + 1, c0 = f.x0 >> 5;
-                int ncell = (f.x1 >> 5) - c0 + 1, nrows = f.r1 - f.r0 + 1;
-                if (ncell > S.pxc || nrows > S.ry) { if (lane == 0) lds_store_i(&ctl->err, 2); ncell = min(ncell, S.pxc); nrows = min(nrows, S.ry); }
-                const int pitch = ncell * 128, img_bytes = nrows * pitch;
-                const int np = (ng * img_bytes + kPage - 1) / kPage;
-                const int pos = head + np <= kPages ? head : 0;
-                // Places are given out in group order (ctl->alloc passes from wave to wave): a later group that took its
-                // pages first could sit on pages an earlier group needs while the consumers wait for that earlier group.
-                bool ok = ke - pr < kTab && __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->alloc)) == gi;
-                if (ok) {
-                    bool busy = false;
-                    for (int b0 = 0; b0 < np; b0 += 64)
-                        if (b0 + lane < np) busy = busy || !(lds_load_i(&ctl->owner[pos + b0 + lane]) < pr);
-                    ok = !any_(busy);
-                }
-                if (!ok) {
-#ifdef VV_SWEEP_DEBUG
-                    if (lane == 0) { int *d = ctl->dbg[lw]; d[0] = kn; d[1] = ke; d[2] = pr; d[3] = pos; d[4] = np; d[5] = head; d[6] = gi; d[7] = idle; }
-#endif
-                    // no room: wait without taking issue slots from the consumers that have to make it
-                    __builtin_amdgcn_s_setprio(0);
-                    __builtin_amdgcn_s_sleep(4);
-                    if (INSTR) t_idle += __builtin_readcyclecounter() - tt;
-                    if (++idle > (1 << 22)) { if (lane == 0) lds_store_i(&ctl->err, 1); bail = true; break; }
-                    continue;
-                }
-                idle = 0;
-                __builtin_amdgcn_s_setprio(3);       // the copies are on every consumer's critical path: issue them ahead of the arithmetic
-                for (int b0 = 0; b0 < np; b0 += 64)
-                    if (b0 + lane < np) lds_store_i(&ctl->owner[pos + b0 + lane], ke);
-                const int img = kRingOff + pos * kPage;
-                if (lane < ng) {
-                    lds_store_i2(&ctl->tab[(kn + lane) & (kTab - 1)], i2v{img + lane * img_bytes - f.r0 * pitch - c0 * 128, pitch});
-                    if (INSTR) { int *bx = ctl->box[(kn + lane) & (kTab - 1)]; bx[0] = c0 * 32; bx[1] = (c0 + ncell) * 32 - 1; bx[2] = f.r0; bx[3] = f.r0 + nrows - 1; }
-                }
-                if (lane == 0) lds_store_i(&ctl->alloc, gi + 1);         // the next group may take its place (after the owner marks above: LDS is in order)
-                const int sa = kmul * kn + kadd;
-                const char *gp = (const char *)V.data + (int64_t)sa * (int64_t)Ss + (uint64_t)f.r0 * Sr + (uint64_t)c0 * 128u + (uint32_t)lane * 16u;
-                const int64_t gstep = (int64_t)kmul * (int64_t)Ss - (int64_t)nrows * (int64_t)Sr;    // last row of a slice -> first row of the next
-                int lb = img;
-                if (lane < 8 * ncell) {              // one exec mask for the whole group
-#pragma unroll 1
-                    for (int j = 0; j < ng; ++j) {
-#pragma unroll 1
-                        for (int rr = 0; rr < nrows; ++rr) {
-#ifndef VV_SWEEP_DUMMY_LOADER            // experiment build: the bookkeeping without the copies (rate of the consumers alone; pixels are wrong)
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
-                                                             (__attribute__((address_space(3))) void *)(lds + lb), 16, 0, 0);
-#endif
-                            gp += Sr; lb += pitch;
-                        }
-                        gp += gstep;
-                    }
-                }
-                __builtin_amdgcn_s_setprio(0);
-                pk = kn; pn = ng * nrows;
-                head = pos + np; kn = ke + 1; ++gi;
-                if (INSTR && lane == 0) atomicAdd(counter + 5, (unsigned long long)ng * nrows * ncell * 128ull);
-                if (INSTR) t_issue += __builtin_readcyclecounter() - tt;
-            }
-        }
-        wait_vm<0>();                     // nothing of this wave may land in LDS after it has gone
-        // open the gate for good: a consumer that asked for more than kmax would otherwise wait forever (it cannot,
-        // but a wrong pixel beats a hung GPU)
-        if (lane == 0) lds_store_i(&ctl->landed[lw], kInf);
-        if (INSTR && lane == 0) {
-            atomicAdd(counter + 8, t_issue); atomicAdd(counter + 9, t_land); atomicAdd(counter + 10, t_pub); atomicAdd(counter + 11, t_idle);
-            atomicAdd(counter + 12, t_pro);
-        }
-        (void)bail; (void)pn;
-        return;
-    }
-
-    // =========================================================================================
-    // consumer waves: 32 x 2 pixels each, wx x wy of them tile the block's tile_w x tile_h pixels
-    // =========================================================================================
+    // ---- this lane's ray ----
     const int x = x0 + (wave % S.wx) * 32 + (lane & 31), y = y0 + (wave / S.wx) * 2 + (lane >> 5);
     const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax = P.H >= 2 ? P.H - 2 : 0;
     const bool in_frame = x <= xmax && y <= ymax && row_owned(P, y);
@@ -350,139 +213,190 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
     }
     if (!alive) { r.upper = -1.f; r.dist0 = 0.f; r.sstep = 1.f; r.origin = mk3(0, 0, 0); r.dir = r.origin; r.sdir = r.origin; }
 
-    // slices this ray can touch, with a margin: positions at both ends of [dist0, upper]
+    // ---- tile-wide quantities: the slices the tile's rays can touch (with a margin), the block's reference position
+    //      (the least advanced first sample) and the extreme slopes ----
+    float kc1 = 0.f, kD = 1.f;                   // position of the lane's first sample along the sweep, slices per sample step
+    bool ok = false;
     {
+        const float isc = MAJOR == 2 ? P.inv_scale[2] : P.inv_scale[1];
         int klo = kInf, khi = -1;
         if (alive && r.dist0 < r.upper) {
             const float os = MAJOR == 2 ? r.origin.z : r.origin.y, dsv = MAJOR == 2 ? r.dir.z : r.dir.y;
-            const float isc = MAJOR == 2 ? P.inv_scale[2] : P.inv_scale[1];
             const float ta = __builtin_fmaf((os + dsv * r.dist0) - 0.5f, isc, 0.5f), tb = __builtin_fmaf((os + dsv * r.upper) - 0.5f, isc, 0.5f);
-            const float za = ta * (float)ns - 0.5f, zb = tb * (float)ns - 0.5f;
+            const float za = ta * fns - 0.5f, zb = tb * fns - 0.5f;
             const int slo = (int)fminf(fmaxf(floorf(fminf(za, zb) - 1.5f), 0.f), (float)(ns - 1));
             const int shi = (int)fminf(fmaxf(floorf(fmaxf(za, zb) + 1.5f), 0.f), (float)(ns - 1)) + 1;
             klo = S.sgn > 0 ? slo : ns - shi; khi = S.sgn > 0 ? shi : ns - slo;
         }
-        klo = wave_min_i(klo); khi = wave_max_i(khi);
-        if (lane == 0 && khi >= 0) { atomicMin(&ctl->kmin, klo); atomicMax(&ctl->kmax, khi); lds_store_i(&ctl->progress[wave], 0); }
+        const float p1 = MAJOR == 2 ? r.origin.z + r.sdir.z : r.origin.y + r.sdir.y;              // first sample (dist0 = 0: no cutting plane here)
+        const float z1 = __builtin_fmaf(p1 - 0.5f, isc, 0.5f) * fns - 0.5f;
+        const float dz = (MAJOR == 2 ? r.sdir.z : r.sdir.y) * isc * fns;
+        kc1 = S.sgn > 0 ? z1 : fns - z1;
+        kD = fabsf(dz);
+        ok = alive && r.dist0 < r.upper && kD > 1e-6f && kD < 64.f && kc1 == kc1;
+        klo = wave_min_fast(klo); khi = -wave_min_fast(-khi);
+        const int cb = wave_min_fast(ok ? pos_bits(kc1) : 0x7f800000);
+        const int d0 = wave_min_fast(ok ? __float_as_int(kD) : 0x7f800000), d1 = wave_min_fast(ok ? -__float_as_int(kD) : 0);
+        if (lane == 0 && khi >= 0) { atomicMin(&ctl->kmin, klo); atomicMax(&ctl->kmax, khi); }
+        if (lane == 0) { atomicMin(&ctl->cref, cb); atomicMin(&ctl->dmin, d0); atomicMin(&ctl->dmax, d1); }
     }
     __syncthreads();
-    const int kmin = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmin));
-
-    // ---------------------------------------------------------------------------------------------------------------
-    // Per-wave skewed lock step (round 3; round 2's consumer paced every LANE by itself and spent 386 VALU instructions
-    // per step on that).  As in march_skew_kernel (vv_raymarch.hip) lane L takes its sample s = tau - o_L at wave step
-    // tau, with o_L chosen so that all lanes of the wave sit within about one sample spacing of a common position along
-    // the sweep axis; every lane still executes exactly the reference's operations for its ray.  The wave's slice window
-    // of a trip -- [floor(min_L kc_L), floor(max_L kc_L) + 1] in sweep positions -- is then a few slices wide and is
-    // tracked with scalars: kc_L(tau) = A_L + tau * D_L per lane (positions are affine in the sample number), the wave
-    // extremes are re-anchored by two wave reductions every kAnchor steps and run on the extreme slopes in between.
-    // One scalar test per trip against `landed`, one scalar release through progress[wave]; no per-lane waiting.
-    // A wave whose window would not fit the ring (lanes entering through different faces at the cube's silhouette) or
-    // whose live rays have all terminated early takes its samples by direct gathers instead (`tail`).
-    // ---------------------------------------------------------------------------------------------------------------
-    constexpr int U = 2;                      // samples per trip (LDS latency is short: depth buys nothing, window costs ring)
-    constexpr int kAnchor = 16;
-    constexpr float kWinMargin = 0.125f;      // slices; the affine model is exact to ~1e-3
-    const float fns = (float)ns;
-    float kA = 0.f, kD = 1.f;                 // kc_L(tau) = kA + tau * kD
+    const int kmin = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmin)), kmaxT = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmax));
+    float Dmin = __int_as_float(__builtin_amdgcn_readfirstlane(lds_load_i(&ctl->dmin)));
+    float Dmax = __int_as_float(-__builtin_amdgcn_readfirstlane(lds_load_i(&ctl->dmax)));
+    // the lane's offset: speed only -- any value gives the same pixels
     int o = 0;
-    float Dmin = 1.f, Dmax = 1.f;
+    float kA = 0.f;                               // kc_L(tau) = kA + tau * kD
     {
-        const float isc = MAJOR == 2 ? P.inv_scale[2] : P.inv_scale[1];
-        const float p1 = MAJOR == 2 ? r.origin.z + r.sdir.z : r.origin.y + r.sdir.y;              // first sample (dist0 = 0: no cutting plane here)
-        const float z1 = __builtin_fmaf(p1 - 0.5f, isc, 0.5f) * fns - 0.5f;                          // its slice coordinate
-        const float dz = (MAJOR == 2 ? r.sdir.z : r.sdir.y) * isc * fns;
-        const float kc1 = S.sgn > 0 ? z1 : fns - z1;
-        kD = fabsf(dz);
-        const bool ok = alive && kD > 1e-6f && kc1 == kc1;
-        int m = __float_as_int(ok ? fmaxf(kc1 + 1024.f, 0.f) : INFINITY);                            // (+1024: ordered as integers also below 0)
-        m = wave_min_fast(m);
-        const float cref = __int_as_float(m) - 1024.f;
-        if (ok) {
-            const float q = rintf((kc1 - cref) / kD);
-            o = q >= 0.f ? (q < 30.f ? (int)q : 30) : 0;
-        }
+        const float cref = bits_pos(__builtin_amdgcn_readfirstlane(lds_load_i(&ctl->cref)));
+        if (ok) { const float q = rintf((kc1 - cref) / kD); o = q >= 0.f ? (q < 30.f ? (int)q : 30) : 0; }
         kA = kc1 - (float)(o + 1) * kD;
-        // (positive floats order like their bit patterns: minimum / maximum by the integer reductions)
-        Dmin = __int_as_float(wave_min_fast(ok ? __float_as_int(kD) : 0x7f800000));
-        Dmax = __int_as_float(-wave_min_fast(ok ? -__float_as_int(kD) : 0));
-        if (!(Dmin <= Dmax)) { Dmin = 1.f; Dmax = 1.f; }                      // no lane of this wave marches
     }
+    int ring = (kmaxT >= kmin && Dmin <= Dmax && Dmax < 64.f) ? 1 : 0;        // block-uniform: the block streams slices through LDS
 
+    // ---- the copy side: frustum of the tile, deterministic ring layout ----
+    Frustum F;
+    tile_frustum<MAJOR>(P, V, min(x0, P.W - 1), min(y0, P.H - 1), min(x0 + tile_w - 1, P.W - 1), min(y0 + tile_h - 1, P.H - 1), F);
+    FootLin FL;
+    foot_linear(F, S.sgn > 0, FL);
+    const uint64_t Sr = MAJOR == 2 ? V.row_bytes : V.slice_bytes;       // bytes between rows of the image
+    const uint64_t Ss = MAJOR == 2 ? V.slice_bytes : V.row_bytes;       // bytes between slices
+    int issued_k = kmin - 1, head = 0;           // highest slice whose copies are issued; next free page (every wave: same values)
+    int cnt1 = 0, cnt2 = 0, cnt3 = 0;            // copies this wave issued one / two / three trips ago ...
+    int hi1 = kmin - 1, hi2 = kmin - 1, hi3 = kmin - 1;   // ... and the highest slice issued by the end of that trip
+    unsigned long long staged = 0;
+
+    // ---- march state (skewed lock step, as march_skew_kernel) ----
     float dist = r.dist0;
     bool ert = false, stop = false, active = alive, lastc = false;
     int i = 31 - o;                           // next sample of the lane's chunk; 31 = open the next chunk now
     int n = 0, chunks = 0;
     float px = 0.f, py = 0.f, pz = 0.f;
-    int tail = 0;                             // wave-uniform: the wave takes its samples by direct gathers (it has left the ring)
-    int pw = 0;                               // published progress of this wave
-    int tau = 1;                              // wave step of the trip's first slot
-    int tau0 = -1000000;                      // step of the last re-anchoring
-    float lo0 = 0.f, hi0 = 0.f;               // wave extremes of kc at tau0
-    const int kmaxT = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->kmax));
-    const int tmax = P.max_chunks * 30 + 30 + U;
-    int stall_run = 0, n_iter = 0, n_stall = 0;
+    int tau = 1;                              // block step of the trip's first slot (ring mode: the same in every wave)
+    int tau0 = 1, apar = 0, trip = 0;
+    float lo0 = 0.f, hi0 = 0.f;               // block extremes of kc at tau0
+    const int tmax = P.max_chunks * 30 + 30 + kU;
+    int n_trips = 0, n_gather_trips = 0;
     const unsigned long long t_loop0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-    for (int t = 0; t < tmax; t += U) {
-        const bool pending = active && !(lastc && i > n) && !(P.ert_true && ert);
-        if (!__any(pending)) break;
-        // every lane idle until its next chunk boundary: jump there (march_skew_kernel)
-        if (!__any(i <= n && !stop)) {
-            int d = pending ? 31 - i : 64;
-            d = wave_min_fast(d);
-            i += d; tau += d;
-        }
-        // all live rays terminated early: the remaining samples are one per 30-sample chunk -- not worth the stream
-        if (!tail && !__any(pending && !ert)) {
-            tail = 1;
-            if (lane == 0) lds_store_i(&ctl->progress[wave], kInf);
-        }
-        if (!tail) {
-            // ---- the wave's slice window for this trip ----
-            if (tau - tau0 >= kAnchor) {
-                const float kc = fminf(fmaxf(kA + (float)tau * kD, (float)kmin), (float)kmaxT);     // pending lanes; >= 0
-                const int mn = wave_min_fast(pending ? __float_as_int(kc) : 0x7f800000);
-                const int mx = wave_min_fast(pending ? -__float_as_int(kc) : 0);
-                lo0 = __int_as_float(mn); hi0 = __int_as_float(-mx); tau0 = tau;
-                if (!(hi0 - lo0 + (float)kAnchor * (Dmax - Dmin) + (float)U * Dmax + 2.f * kWinMargin + 3.f <= (float)S.wmax)) {
-                    // the window does not fit the ring: this wave marches on direct gathers from here on
-                    tail = 1;
-                    if (lane == 0) lds_store_i(&ctl->progress[wave], kInf);
-                }
-            }
-        }
-        tail = __builtin_amdgcn_readfirstlane(tail);
-        if (!tail) {
-            const float dt0 = (float)(tau - tau0);
-            const float lo_f = lo0 + dt0 * Dmin - kWinMargin, hi_f = hi0 + (dt0 + (float)(U - 1)) * Dmax + kWinMargin;
-            const int need_lo = __builtin_amdgcn_readfirstlane(max((int)floorf(lo_f), kmin));
-            const int need_hi = __builtin_amdgcn_readfirstlane(min((int)floorf(hi_f) + 1, kmaxT));
-            if (need_lo > pw) { pw = need_lo; if (lane == 0) lds_store_i(&ctl->progress[wave], pw); }
-            for (;;) {
-                const i4v l4 = lds_load_i4(ctl->landed);
-                const int kl = __builtin_amdgcn_readfirstlane(min(min(l4.x, l4.y), min(l4.z, l4.w)));
-                if (kl > need_hi) break;
-                if (INSTR) ++n_stall;
-                __builtin_amdgcn_s_sleep(1);
-                if (++stall_run > (1 << 21)) {               // watchdog: a wrong pixel beats a hung GPU
-                    if (lane == 0) { lds_store_i(&ctl->err, 3); lds_store_i(&ctl->progress[wave], kInf); }
-                    tail = 1;
-                    break;
-                }
-            }
-            stall_run = 0;
-            asm volatile("" ::: "memory");        // the flag is read before any slice data of this step
-        }
-        ++n_iter;
-        if (INSTR) slots += (unsigned long long)U * 64ull;
+    auto publish_anchor = [&](int par, int at_tau, bool pend) {
+        const float kc = kA + (float)at_tau * kD;
+        const int mn = wave_min_fast(pend ? pos_bits(kc) : 0x7f800000), mx = wave_min_fast(pend ? -pos_bits(kc) : 0);
+        if (lane == 0 && mn != 0x7f800000) { atomicMin(&ctl->anc[par][0], mn); atomicMin(&ctl->anc[par][1], mx); }
+    };
+    if (ring) {
+        publish_anchor(0, 1, active);
+        __syncthreads();
+        const int a0 = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->anc[0][0])), a1 = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->anc[0][1]));
+        if (a0 == 0x7f800000) ring = 0;                                       // no ray of the tile marches
+        lo0 = bits_pos(a0); hi0 = bits_pos(-a1);
+    }
 
-        uint32_t idx[U];
-        int iu[U];
-        bool lv[U];
-        float ttx[U], tty[U], ttz[U];
+    for (int t = 0; t < tmax; t += kU) {
+        const bool pending = active && !(lastc && i > n) && !(P.ert_true && ert);
+        if (!ring && !__any(pending)) break;
+        if (ring) {
+            // ================= copy side of the trip (identical scalar state in every wave) =================
+            const float dt0 = (float)(tau - tau0);
+            const float lo_prev = lo0 + (dt0 - (float)kU) * Dmin - kWinMargin;                       // the previous trip may still be computing
+            const float hi_now = hi0 + (dt0 + (float)(kU - 1)) * Dmax + kWinMargin;
+            const float hi_ahead = hi0 + (dt0 + (float)(kU - 1 + S.ahead * kU)) * Dmax + kWinMargin;
+            const int lo_free = max((int)floorf(lo_prev), kmin);                                   // slices below are read by nobody any more
+            const int need_hi = min((int)floorf(hi_now) + 1, kmaxT);
+            const int target = min(min((int)floorf(hi_ahead) + 1, kmaxT), lo_free + (kTab - 2));
+            int cnt0 = 0;
+            while (issued_k < target) {
+                const int k = issued_k + 1, sl = kmul * k + kadd;
+                Foot f = footprint(FL, sl, nx, nr);
+                f.x0 = __builtin_amdgcn_readfirstlane(f.x0); f.x1 = __builtin_amdgcn_readfirstlane(f.x1);
+                f.r0 = __builtin_amdgcn_readfirstlane(f.r0); f.r1 = __builtin_amdgcn_readfirstlane(f.r1);
+                const int c0 = f.x0 >> 5;
+                int ncell = (f.x1 >> 5) - c0 + 1, nrows = f.r1 - f.r0 + 1;
+                if (ncell > S.pxc || nrows > S.ry) { if (lane == 0) lds_store_i(&ctl->err, 2); ncell = min(ncell, S.pxc); nrows = min(nrows, S.ry); }
+                const int pitch = ncell * 128, np = (nrows * pitch + kPage - 1) / kPage;
+                const int pos = head + np <= kPages ? head : 0;
+                bool busy = false;
+                for (int b0 = 0; b0 < np; b0 += 64)
+                    if (b0 + lane < np) { const int ow = lds_load_i(&ctl->owner[pos + b0 + lane]); busy = busy || !(ow < lo_free || ow == k); }
+                if (any_(busy)) break;                                        // no room yet: next trip
+                const int img = kRingOff + pos * kPage;
+                if (wave == 0) {
+                    for (int b0 = 0; b0 < np; b0 += 64)
+                        if (b0 + lane < np) lds_store_i(&ctl->owner[pos + b0 + lane], k);
+                    if (lane == 0) {
+                        lds_store_i2(&ctl->tab[k & (kTab - 1)], i2v{img - f.r0 * pitch - c0 * 128, pitch});
+                        if (INSTR) { int *bx = ctl->box[k & (kTab - 1)]; bx[0] = c0 * 32; bx[1] = (c0 + ncell) * 32 - 1; bx[2] = f.r0; bx[3] = f.r0 + nrows - 1; }
+                    }
+                }
+                // this wave's rows of the image: one LDS-DMA instruction per row, lane l copies bytes [16 l, 16 l + 16)
+                int rr = wave + k; rr -= (rr / NW) * NW;                      // rotate the rows over the waves from slice to slice
+                if (rr < nrows) {
+                    const char *gp = (const char *)V.data + (int64_t)sl * (int64_t)Ss + (uint64_t)(f.r0 + rr) * Sr + (uint64_t)c0 * 128u + (uint32_t)lane * 16u;
+                    int lb = img + rr * pitch;
+                    const uint64_t gstep = (uint64_t)NW * Sr;
+                    const int lstep = NW * pitch;
+                    for (; rr < nrows; rr += NW) {
+                        if (lane < 8 * ncell)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                                             (__attribute__((address_space(3))) void *)(lds + lb), 16, 0, 0);
+                        gp += gstep; lb += lstep; ++cnt0;
+                    }
+                }
+                if (INSTR && wave == 0) staged += (unsigned long long)nrows * pitch;
+                head = pos + np; issued_k = k;
+            }
+            int bail = 0;
+            if (issued_k < need_hi) {
+                // the slices this very trip reads could not be placed: the block's window does not fit the ring (rays that
+                // enter through different faces at the cube's silhouette, strongly diverging rays).  Every wave sees the same
+                // numbers: the block leaves the ring here and marches on direct gathers.
+                bail = 1;
+                if (lane == 0) lds_store_i(&ctl->err, 4);
+            } else {
+                // wait for THIS wave's rows of the slices <= need_hi: everything but the copies issued after them
+                int nwait = 0;
+                if (hi3 >= need_hi) nwait = cnt0 + cnt1 + cnt2;
+                else if (hi2 >= need_hi) nwait = cnt0 + cnt1;
+                else if (hi1 >= need_hi) nwait = cnt0;
+                wait_vm_n(nwait);
+            }
+            cnt3 = cnt2; cnt2 = cnt1; cnt1 = cnt0; hi3 = hi2; hi2 = hi1; hi1 = issued_k;
+            // the one barrier of the trip: every wave's rows have landed; does any ray still need the stream?
+            const int still = __syncthreads_or((__any(pending && !ert) ? 1 : 0) && !bail);
+            if (!still) {
+                ring = 0;
+                wait_vm<0>();                        // nothing of this wave may land in LDS after the block has moved on
+            } else if (trip > 0 && trip % kAnchorTrips == 0) {
+                // the anchors published during the previous trip (for this trip's first step)
+                const int a0 = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->anc[apar ^ 1][0])), a1 = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->anc[apar ^ 1][1]));
+                if (a0 != 0x7f800000) { lo0 = bits_pos(a0); hi0 = bits_pos(-a1); tau0 = tau; }
+                if (threadIdx.x == 0) { ctl->anc[apar][0] = 0x7f800000; ctl->anc[apar][1] = 0; }   // (read last kAnchorTrips trips ago)
+                apar ^= 1;
+            }
+            ++trip;
+        } else {
+            // direct gathers: every lane idle until its next chunk boundary -> jump there (march_skew_kernel)
+            if (!__any(i <= n && !stop)) {
+                int d = pending ? 31 - i : 64;
+                d = wave_min_fast(d);
+                i += d; tau += d;
+            }
+            ++n_gather_trips;
+        }
+        ++n_trips;
+        if (!__any(pending)) {                    // a wave whose rays are done keeps copying its rows for the others
+            tau += kU;
+            if (ring && (trip % kAnchorTrips) == 0) publish_anchor(apar ^ 1, tau, false);
+            continue;
+        }
+        if (INSTR) slots += (unsigned long long)kU * 64ull;
+
+        uint32_t idx[kU];
+        int iu[kU];
+        bool lv[kU];
+        float ttx[kU], tty[kU], ttz[kU];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < kU; ++u) {
             // ---- chunk boundary of this lane: close the old chunk (:277), open the next (:248-249) ----
             if (__any(i == 31)) {
                 if (i == 31) {
@@ -509,7 +423,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             ttx[u] = tx; tty[u] = ty; ttz[u] = tz;
             iu[u] = i; lv[u] = i <= n;
             ++i;
-            if (!tail) {
+            if (ring) {
                 uint32_t ix, iy, iz;
                 const float wx = axis_coord<TEX8>(tx, (float)V.nx, (float)(V.nx - 1), ix);
                 const float wy = axis_coord<TEX8>(ty, (float)V.ny, (float)(V.ny - 1), iy);
@@ -532,22 +446,23 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
                 const float f0 = __builtin_fmaf(wy, e10 - e00, e00);
                 const float f1 = __builtin_fmaf(wy, e11 - e01, e01);
                 const float L = __builtin_fmaf(wz, f1 - f0, f0);
-                uint32_t id = min((uint32_t)(L * 255.0f), 255u);
+                const uint32_t id = min((uint32_t)(L * 255.0f), 255u);
                 idx[u] = inb ? id : 0u;
-                if (INSTR && lv[u] && inb) {
+                if (INSTR && lv[u] && inb && !stop && !(P.ert_true && ert)) {
                     const int *bx0 = ctl->box[k0 & (kTab - 1)], *bx1 = ctl->box[(k0 + kmul) & (kTab - 1)];
                     const bool okb = (int)ix >= bx0[0] && (int)ix + 1 <= bx0[1] && ir >= bx0[2] && ir + 1 <= bx0[3] &&
                                      (int)ix >= bx1[0] && (int)ix + 1 <= bx1[1] && ir >= bx1[2] && ir + 1 <= bx1[3];
-                    // (a sample masked by `stop` / early termination below may lie ahead of the window: only live ones count)
-                    if (!okb && !stop && !(P.ert_true && ert)) ++misses;
+                    // ... and both images must still be the ones of these slices (a page handed on too early would read as a miss)
+                    const int o0 = lds_load_i(&ctl->owner[(int)((p0 - lds) - kRingOff) >> 10]), o1 = lds_load_i(&ctl->owner[(int)((p1 - lds) - kRingOff) >> 10]);
+                    if (!okb || o0 != k0 || o1 != k0 + kmul) ++misses;
                 }
             } else {
                 idx[u] = V.big ? sample_index<VV_VOXEL_F32, TEX8, true>(V, tx, ty, tz) : sample_index<VV_VOXEL_F32, TEX8, false>(V, tx, ty, tz);
             }
         }
-        tau += U;
+        tau += kU;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < kU; ++u) {
             if (iu[u] == 1) stop = false;                    // the inner loop's break flag is per chunk (:272-274)
             const bool live = lv[u] && !stop && !(P.ert_true && ert);
             float cr, cg, cb, ca;
@@ -571,27 +486,35 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             stop = stop || hit;
             ert = ert || hit;
         }
+        // ---- the block's extremes at the next trip's first step, published one trip ahead of their use (`trip` already counts
+        //      this trip: the next one re-anchors when it is a multiple of kAnchorTrips) ----
+        if (ring && (trip % kAnchorTrips) == 0) {
+            const bool pend2 = active && !(lastc && i > n) && !(P.ert_true && ert);
+            publish_anchor(apar ^ 1, tau, pend2);
+        }
     }
-    if (!tail && lane == 0) lds_store_i(&ctl->progress[wave], kInf);
+    wait_vm<0>();                             // (a block that never left the ring inside the loop: tmax)
     if (S.trace && wave == 0 && lane == 0) {
         unsigned long long *tr = S.trace + 8ull * blockIdx.x;
         tr[0] = t_blk0; tr[1] = t_loop0; tr[2] = __builtin_amdgcn_s_memrealtime();
         tr[3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63508);
-        tr[4] = ((unsigned long long)trow << 32) | (unsigned)tcol; tr[5] = ((unsigned long long)(unsigned)kmaxT << 32) | (unsigned)kmin; tr[6] = ((unsigned long long)(unsigned)n_stall << 32) | (unsigned)n_iter; tr[7] = 1;
+        tr[4] = ((unsigned long long)trow << 32) | (unsigned)tcol; tr[5] = ((unsigned long long)(unsigned)kmaxT << 32) | (unsigned)kmin; tr[6] = ((unsigned long long)(unsigned)n_gather_trips << 32) | (unsigned)n_trips; tr[7] = 1;
     }
 
     if (in_frame) {
         if (GRAY) { res_g = res_r; res_b = res_r; }
         pixels[(size_t)y * P.W + x] = write_zero ? 0u : pack_rgba(res_r, res_g, res_b, res_a);
     }
+    // errors are always reported (a clamped footprint would mean wrong pixels): counter + 7 holds four 16-bit counts, codes 1..4
+    // (code 4 -- a block left the ring because its window did not fit -- is a statistic, not an error: pixels are right)
+    if (lane == 0 && wave == 0) { const int e = lds_load_i(&ctl->err); if (e) atomicAdd(counter + 7, 1ull << (16 * (e - 1))); }
     if (INSTR) {
-        for (int o = 32; o > 0; o >>= 1) { executed += __shfl_down(executed, o); misses += __shfl_down(misses, o); }
+        for (int q = 32; q > 0; q >>= 1) { executed += __shfl_down(executed, q); misses += __shfl_down(misses, q); }
         if (lane == 0 && executed) atomicAdd(counter, executed);
         if (lane == 0 && slots) atomicAdd(counter + 1, slots);
         if (lane == 0 && misses) atomicAdd(counter + 4, misses);
-        if (lane == 0 && n_stall) atomicAdd(counter + 6, (unsigned long long)n_stall);
-        if (lane == 0 && tail) atomicAdd(counter + 13, 1ull);                                     // waves that finished on direct gathers
-        if (lane == 0 && wave == 0) { const int e = lds_load_i(&ctl->err); if (e) atomicAdd(counter + 7, 1ull << (16 * (e - 1))); }   // four 16-bit counts: codes 1..4
+        if (lane == 0 && staged) atomicAdd(counter + 5, staged);
+        if (lane == 0) { atomicAdd(counter + 6, (unsigned long long)n_trips); atomicAdd(counter + 13, (unsigned long long)n_gather_trips); }
     }
 }
 
@@ -603,7 +526,7 @@ static void launch_one(const MarchArgs &a, hipStream_t s)
     auto kern = sweep_kernel<MAJOR, TEX8, GRAY, INSTR>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3((unsigned)((S.nc + S.nl) * 64)), (size_t)S.lds_bytes, s,
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3((unsigned)(S.nc * 64)), (size_t)S.lds_bytes, s,
                        a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, S);
 }
 template <int MAJOR>
@@ -703,13 +626,13 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     S.major = best; S.sgn = best_sgn;
     // tile shape: wx x wy waves of 32 x 2 pixels.  Wide and short, so that a slice's image has few, long rows
     // (one LDS-DMA instruction per row) and the rim the neighbours re-read is small.
-    S.nl = 3; S.wx = 3; S.wy = 4;
-    if (req.nl >= 1 && req.nl <= 4) S.nl = req.nl;
+    S.nl = 0; S.wx = 2; S.wy = 4;              // (every wave copies: no loader waves)
     if (req.wx >= 1 && req.wx <= 8) S.wx = req.wx;
     if (req.wy >= 1 && req.wy <= 14) S.wy = req.wy;
-    S.group = 3;                             // slices per allocation / confirmation unit of the loaders
-    if (req.group >= 1 && req.group <= 8) S.group = req.group;
-    if (S.wx * S.wy + S.nl > 16) VV_NO("too many waves");
+    S.group = 1;
+    S.ahead = 2;                             // trips the copies run ahead of the march
+    if (req.ahead >= 0 && req.ahead <= 3) S.ahead = req.ahead;
+    if (S.wx * S.wy > 16) VV_NO("too many waves");
     const bool forced = req.wx >= 1 || req.wy >= 1;
     for (;;) {
         S.nc = S.wx * S.wy;
@@ -755,31 +678,20 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
         S.ry = std::min(S.ry, nr + 1);
         S.slot_bytes = S.pxc * 128 * S.ry;                               // the largest image of a slice
         S.ring = (kPages * kPage) / S.slot_bytes;                        // slices of that size the ring holds (it holds more of the smaller ones)
-        if (S.pxc <= 8 && S.ry <= kMaxChunks && S.ring >= 12) break;      // a consumer wave's window (~8-10 slices) + two groups must fit
+        // the block's window (~8-10 slices) + the slices in flight must fit; a forced shape may try its luck (a block whose window
+        // does not fit falls back to gathers by itself)
+        if (S.pxc <= 8 && S.ry <= kMaxChunks && S.ring >= (forced ? 6 : 10)) break;
         // footprint too large for the LDS (sparse pixels): smaller tiles, else no sweep
         if (verbose) fprintf(stderr, "sweep: tile %dx%d waves needs pxc %d ry %d ring %d\n", S.wx, S.wy, S.pxc, S.ry, S.ring);
         if (forced) VV_NO("forced tile shape does not fit");
         if (S.wy > 2) S.wy -= 1; else if (S.wx > 1) { S.wx -= 1; S.wy = 4; } else VV_NO("footprint does not fit the LDS");
     }
     (void)nr;
-    // A sample may interpolate between the last slice of one group and the first of the next, and the loaders can only
-    // refill behind both: three groups of the largest size must fit or the ring can lock up.  One row of slack per group
-    // for the rounding to pages.
-    {
-        const int gmax = (kPages * kPage) / (3 * (S.slot_bytes + kPage));
-        if (gmax < 1) VV_NO("three groups do not fit the ring");
-        S.group = std::min(S.group, gmax);
-        if (S.group * S.ry > 62) S.group = std::max(1, 62 / S.ry);             // a group's copies must fit the 6-bit vmcnt
-        // Widest slice window a consumer wave may hold (in slices of the largest size): the ring must also hold the group being
-        // landed, and pages come free only group-wise (up to group - 1 released slices stay resident)
-        while (S.group > 1 && S.ring - 2 * S.group < 9) --S.group;
-        S.wmax = S.ring - 2 * S.group;
-        if (S.wmax < 6) VV_NO("the ring is too small for a wave's slice window");
-    }
+    S.wmax = S.ring;
     S.lds_bytes = kRingOff + kPages * kPage;
     S.order = nullptr; S.n_order = 0; S.trace = nullptr;
     S.enabled = 1;
-    if (verbose) fprintf(stderr, "sweep: axis %d sgn %d, tile %dx%d px (%d+%d waves), image <= %d cells x %d rows, group %d, %d x %d tiles\n", S.major, S.sgn, 32 * S.wx, 2 * S.wy, S.nc, S.nl, S.pxc, S.ry, S.group, S.ntx, S.nty);
+    if (verbose) fprintf(stderr, "sweep: axis %d sgn %d, tile %dx%d px (%d waves), image <= %d cells x %d rows (ring: %d of that size), %d trips ahead, %d x %d tiles\n", S.major, S.sgn, 32 * S.wx, 2 * S.wy, S.nc, S.pxc, S.ry, S.ring, S.ahead, S.ntx, S.nty);
 #undef VV_NO
 }
 
