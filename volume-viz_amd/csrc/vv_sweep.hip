@@ -55,7 +55,8 @@ struct Ctl {                                   // control block in LDS
     int dmin, dmax;                            // extreme slopes of the block's rays, slices per step (float bits, -bits)
     int err;
     int anc[2][2];                             // double-buffered anchors: {min, -max} of the pending lanes' positions (offset float bits)
-    int pad_[2];
+    int still[3];                              // trip T, word T % 3: set by a wave that still needs the stream (no static LDS: the ring takes all 160 KB)
+    int pad_[1];
     i2v tab[kTab];                            // per slice k (entry k % kTab): byte address of voxel (x 0, row 0) of its image, row pitch
     int box[kTab][4];                          // per slice: x0, x1, r0, r1 held (instrumented builds check against it)
     int owner[kPages + 2];                     // per ring page: the slice whose image occupies it
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
     if (threadIdx.x == 0) {
         ctl->kmin = kInf; ctl->kmax = -1; ctl->err = 0; ctl->cref = 0x7f800000; ctl->dmin = 0x7f800000; ctl->dmax = 0;
         ctl->anc[0][0] = 0x7f800000; ctl->anc[0][1] = 0; ctl->anc[1][0] = 0x7f800000; ctl->anc[1][1] = 0;
+        ctl->still[0] = 0; ctl->still[1] = 0; ctl->still[2] = 0;
     }
     for (int i = threadIdx.x; i < kPages + 2; i += blockDim.x) ctl->owner[i] = -1;
     __syncthreads();
@@ -362,7 +364,13 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             }
             cnt3 = cnt2; cnt2 = cnt1; cnt1 = cnt0; hi3 = hi2; hi2 = hi1; hi1 = issued_k;
             // the one barrier of the trip: every wave's rows have landed; does any ray still need the stream?
-            const int still = __syncthreads_or((__any(pending && !ert) ? 1 : 0) && !bail);
+            // (word trip % 3: written before this barrier, read after it, cleared two barriers before its next use)
+            const int sw = trip % 3;
+            const bool wave_needs = __any(pending && !ert);
+            if (!bail && lane == 0 && wave_needs) lds_store_i(&ctl->still[sw], 1);
+            __syncthreads();
+            const int still = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->still[sw]));
+            if (threadIdx.x == 0) lds_store_i(&ctl->still[(trip + 2) % 3], 0);
             if (!still) {
                 ring = 0;
                 wait_vm<0>();                        // nothing of this wave may land in LDS after the block has moved on
