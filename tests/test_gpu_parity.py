@@ -439,7 +439,7 @@ def test_sweep_kernel_is_bit_identical(ctx, view, monkeypatch):
             # (the thin 20 x 16 x 200 volume qualifies only along z: in voxel units its rays are too flat along y)
             # (the ragged volumes qualify only for some views: in voxel units their rays may be too flat along the sweep axis)
             assert cnt[5] > 0 or n == 0 or dims[0] != dims[2], f"{what}: the sweep kernel did not run"
-            assert cnt[4] == 0 and cnt[7] == 0, f"{what}: {cnt[4]} samples outside the LDS images, {cnt[7]} blocks flagged an error"
+            assert cnt[4] == 0 and (int(cnt[7]) & 0xFFFFFFFFFFFF) == 0, f"{what}: {cnt[4]} samples outside the LDS images, error counts {int(cnt[7]):#x}"   # (bits 48+: blocks that left the ring for gathers -- a statistic)
             assert_frames_close(got, want, what)
             assert n_got == n, what
             got2 = ctx.render(W, H, cam, options=vv.make_options(**o), fill=0x11)            # the uninstrumented build
@@ -455,7 +455,7 @@ def test_sweep_kernel_is_bit_identical(ctx, view, monkeypatch):
         n_got = ctx.last_sample_count()
         cnt = ctx.debug_counters()
         want, n = O.render(vol, tf, 200, 160, cam_s, options=o, fill=0x22)
-        assert cnt[4] == 0 and cnt[7] == 0
+        assert cnt[4] == 0 and (int(cnt[7]) & 0xFFFFFFFFFFFF) == 0
         assert_frames_close(got, want, f"sweep {view} scaled shard={shard}")
         assert n_got == n
 
@@ -549,7 +549,7 @@ def test_sweep_tile_wider_than_the_frame(ctx, monkeypatch):
         cnt = ctx.debug_counters()
         want, n = O.render(vol, tf, W, H, cam, options=vv.make_options(**o), fill=0x3C)
         what = f"eye {origin} scale {scale} {W}x{H}"
-        assert cnt[4] == 0 and cnt[7] == 0, f"{what}: {cnt[4]} samples outside the LDS images, error flags {cnt[7]:#x}"
+        assert cnt[4] == 0 and (int(cnt[7]) & 0xFFFFFFFFFFFF) == 0, f"{what}: {cnt[4]} samples outside the LDS images, error counts {int(cnt[7]):#x}"
         assert_frames_close(got, want, what)
         assert n_got == n, what
         got2 = ctx.render(W, H, cam, options=vv.make_options(**o), fill=0x3C)
@@ -604,7 +604,7 @@ def test_sweep_kernel_seeded(ctx, seed, monkeypatch):
     want, n_want = O.render(vol, tf, W, H, cam, options=vv.make_options(**o), fill=0x3C)
     what = f"sweep seed {seed}: {vol.shape} {W}x{H} eye {tuple(round(v, 2) for v in cam.origin)} {o}"
     assert cnt[5] > 0, f"{what}: the planner accepted the frame but the sweep kernel staged nothing"
-    assert cnt[4] == 0 and cnt[7] == 0, f"{what}: {cnt[4]} samples outside the LDS images, error flags {cnt[7]:#x}"
+    assert cnt[4] == 0 and (int(cnt[7]) & 0xFFFFFFFFFFFF) == 0, f"{what}: {cnt[4]} samples outside the LDS images, error counts {int(cnt[7]):#x}"
     assert_frames_close(got, want, what)
     assert n_got == n_want, what
     got2 = ctx.render(W, H, cam, options=vv.make_options(**o), fill=0x3C)                  # the uninstrumented build

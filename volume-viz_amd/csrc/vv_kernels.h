@@ -24,6 +24,7 @@ struct SweepArgs {
     int y0, rows_per_band, band_stride_px;   // pixel row of tile row t: y0 + (t / rows_per_band) * band_stride_px + (t % rows_per_band) * 2 wy
     int group;             // (1: slices are placed one by one)
     int ahead;             // trips the copies run ahead of the march
+    int steps;             // sample steps per trip (1 or 2)
     int wmax;              // widest slice window (in slices) a consumer wave may need and still use the ring
     int pxc, ry, ring;     // LDS image of a slice: ry rows of pxc 128-byte cells; `ring` slots (power of two)
     int slot_bytes;        // pxc * 128 * ry

@@ -126,7 +126,7 @@ __device__ __forceinline__ void wait_vm_n(int n)
     }
 }
 
-constexpr int kU = 2;                          // sample steps per trip (LDS latency is short: a deeper trip only widens the window)
+constexpr int kHist = 8;                       // trips the copies may run ahead of the march (S.ahead <= kHist)
 constexpr int kAnchorTrips = 8;                // the block's extremes are re-anchored every so many trips
 constexpr float kWinMargin = 0.125f;           // slices; the affine position model is exact to ~1e-3
 constexpr float kPosOff = 4096.f;              // positions are offset so that their bit patterns order like integers (they can be < 0)
@@ -135,7 +135,9 @@ __device__ __forceinline__ int pos_bits(float kc) { return __float_as_int(fminf(
 __device__ __forceinline__ float bits_pos(int b) { return __int_as_float(b) - kPosOff; }
 
 // ---------------------------------------------------------------------------------------------
-template <int MAJOR, bool TEX8, bool GRAY, bool INSTR>
+// kU: sample steps per trip.  Every step more widens the block's slice window by one sample spacing (two slices on C3) --
+// ring space that is then not in flight --, every step less means a barrier more per sample.
+template <int MAJOR, bool TEX8, bool GRAY, bool INSTR, int kU>
 __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V,
                                                      const float4 *__restrict__ tf,
                                                      const float *__restrict__ rad,
@@ -264,8 +266,9 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
     const uint64_t Sr = MAJOR == 2 ? V.row_bytes : V.slice_bytes;       // bytes between rows of the image
     const uint64_t Ss = MAJOR == 2 ? V.slice_bytes : V.row_bytes;       // bytes between slices
     int issued_k = kmin - 1, head = 0;           // highest slice whose copies are issued; next free page (every wave: same values)
-    int cnt1 = 0, cnt2 = 0, cnt3 = 0;            // copies this wave issued one / two / three trips ago ...
-    int hi1 = kmin - 1, hi2 = kmin - 1, hi3 = kmin - 1;   // ... and the highest slice issued by the end of that trip
+    int cntH[kHist], hiH[kHist];                 // copies this wave issued 1 .. kHist trips ago, and the highest slice issued by the end of that trip
+#pragma unroll
+    for (int h = 0; h < kHist; ++h) { cntH[h] = 0; hiH[h] = kmin - 1; }
     unsigned long long staged = 0;
 
     // ---- march state (skewed lock step, as march_skew_kernel) ----
@@ -356,13 +359,15 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
                 if (lane == 0) lds_store_i(&ctl->err, 4);
             } else {
                 // wait for THIS wave's rows of the slices <= need_hi: everything but the copies issued after them
-                int nwait = 0;
-                if (hi3 >= need_hi) nwait = cnt0 + cnt1 + cnt2;
-                else if (hi2 >= need_hi) nwait = cnt0 + cnt1;
-                else if (hi1 >= need_hi) nwait = cnt0;
+                // (the copies issued in the trips AFTER the last one that had reached need_hi may stay in flight)
+                int nwait = 0, acc = cnt0;
+#pragma unroll
+                for (int h = 0; h < kHist; ++h) { if (hiH[h] >= need_hi) nwait = acc; acc += cntH[h]; }
                 wait_vm_n(nwait);
             }
-            cnt3 = cnt2; cnt2 = cnt1; cnt1 = cnt0; hi3 = hi2; hi2 = hi1; hi1 = issued_k;
+#pragma unroll
+            for (int h = kHist - 1; h > 0; --h) { cntH[h] = cntH[h - 1]; hiH[h] = hiH[h - 1]; }
+            cntH[0] = cnt0; hiH[0] = issued_k;
             // the one barrier of the trip: every wave's rows have landed; does any ray still need the stream?
             // (word trip % 3: written before this barrier, read after it, cleared two barriers before its next use)
             const int sw = trip % 3;
@@ -531,11 +536,19 @@ static void launch_one(const MarchArgs &a, hipStream_t s)
 {
     const SweepArgs &S = a.sweep;
     const unsigned nblocks = S.order ? (unsigned)S.n_order : (unsigned)(((S.nty + 7) / 8) * 8 * S.ntx);
-    auto kern = sweep_kernel<MAJOR, TEX8, GRAY, INSTR>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3((unsigned)(S.nc * 64)), (size_t)S.lds_bytes, s,
-                       a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, S);
+    if (S.steps == 1) {
+        auto kern = sweep_kernel<MAJOR, TEX8, GRAY, INSTR, 1>;
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax); attr_set = true; }
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3((unsigned)(S.nc * 64)), (size_t)S.lds_bytes, s,
+                           a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, S);
+    } else {
+        auto kern = sweep_kernel<MAJOR, TEX8, GRAY, INSTR, 2>;
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax); attr_set = true; }
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3((unsigned)(S.nc * 64)), (size_t)S.lds_bytes, s,
+                           a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, S);
+    }
 }
 template <int MAJOR>
 static void launch_major(const MarchArgs &a, hipStream_t s)
@@ -638,8 +651,10 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     if (req.wx >= 1 && req.wx <= 8) S.wx = req.wx;
     if (req.wy >= 1 && req.wy <= 14) S.wy = req.wy;
     S.group = 1;
-    S.ahead = 2;                             // trips the copies run ahead of the march
-    if (req.ahead >= 0 && req.ahead <= 3) S.ahead = req.ahead;
+    S.steps = 1;                             // sample steps per trip
+    if (req.steps >= 1 && req.steps <= 2) S.steps = req.steps;
+    S.ahead = 6;                             // trips the copies run ahead of the march (as far as the ring has room)
+    if (req.ahead >= 0 && req.ahead <= kHist) S.ahead = req.ahead;
     if (S.wx * S.wy > 16) VV_NO("too many waves");
     const bool forced = req.wx >= 1 || req.wy >= 1;
     for (;;) {
@@ -699,7 +714,7 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     S.lds_bytes = kRingOff + kPages * kPage;
     S.order = nullptr; S.n_order = 0; S.trace = nullptr;
     S.enabled = 1;
-    if (verbose) fprintf(stderr, "sweep: axis %d sgn %d, tile %dx%d px (%d waves), image <= %d cells x %d rows (ring: %d of that size), %d trips ahead, %d x %d tiles\n", S.major, S.sgn, 32 * S.wx, 2 * S.wy, S.nc, S.pxc, S.ry, S.ring, S.ahead, S.ntx, S.nty);
+    if (verbose) fprintf(stderr, "sweep: axis %d sgn %d, tile %dx%d px (%d waves), image <= %d cells x %d rows (ring: %d of that size), %d steps per trip, %d trips ahead, %d x %d tiles\n", S.major, S.sgn, 32 * S.wx, 2 * S.wy, S.nc, S.pxc, S.ry, S.ring, S.steps, S.ahead, S.ntx, S.nty);
 #undef VV_NO
 }
 
