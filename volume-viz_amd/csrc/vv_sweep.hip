@@ -282,6 +282,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
     float lo0 = 0.f, hi0 = 0.f;               // block extremes of kc at tau0
     const int tmax = P.max_chunks * 30 + 30 + kU;
     int n_trips = 0, n_gather_trips = 0;
+    unsigned long long tc_issue = 0, tc_wait = 0, tc_barrier = 0, tc_march = 0, tc0 = 0;   // instrumented builds: cycles per phase
     const unsigned long long t_loop0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     auto publish_anchor = [&](int par, int at_tau, bool pend) {
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             const int need_hi = min((int)floorf(hi_now) + 1, kmaxT);
             const int target = min(min((int)floorf(hi_ahead) + 1, kmaxT), lo_free + (kTab - 2));
             int cnt0 = 0;
+            if (INSTR) tc0 = __builtin_readcyclecounter();
             while (issued_k < target) {
                 const int k = issued_k + 1, sl = kmul * k + kadd;
                 Foot f = footprint(FL, sl, nx, nr);
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
                 if (INSTR && wave == 0) staged += (unsigned long long)nrows * pitch;
                 head = pos + np; issued_k = k;
             }
+            if (INSTR) { const unsigned long long tn = __builtin_readcyclecounter(); tc_issue += tn - tc0; tc0 = tn; }
             int bail = 0;
             if (issued_k < need_hi) {
                 // the slices this very trip reads could not be placed: the block's window does not fit the ring (rays that
@@ -369,12 +372,14 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             for (int h = kHist - 1; h > 0; --h) { cntH[h] = cntH[h - 1]; hiH[h] = hiH[h - 1]; }
             cntH[0] = cnt0; hiH[0] = issued_k;
             // the one barrier of the trip: every wave's rows have landed; does any ray still need the stream?
+            if (INSTR) { const unsigned long long tn = __builtin_readcyclecounter(); tc_wait += tn - tc0; tc0 = tn; }
             // (word trip % 3: written before this barrier, read after it, cleared two barriers before its next use)
             const int sw = trip % 3;
             const bool wave_needs = __any(pending && !ert);
             if (!bail && lane == 0 && wave_needs) lds_store_i(&ctl->still[sw], 1);
             __syncthreads();
             const int still = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->still[sw]));
+            if (INSTR) { const unsigned long long tn = __builtin_readcyclecounter(); tc_barrier += tn - tc0; tc0 = tn; }
             if (threadIdx.x == 0) lds_store_i(&ctl->still[(trip + 2) % 3], 0);
             if (!still) {
                 ring = 0;
@@ -397,6 +402,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             ++n_gather_trips;
         }
         ++n_trips;
+        if (INSTR && !ring) tc0 = __builtin_readcyclecounter();
         if (!__any(pending)) {                    // a wave whose rays are done keeps copying its rows for the others
             tau += kU;
             if (ring && (trip % kAnchorTrips) == 0) publish_anchor(apar ^ 1, tau, false);
@@ -499,6 +505,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             stop = stop || hit;
             ert = ert || hit;
         }
+        if (INSTR) tc_march += __builtin_readcyclecounter() - tc0;
         // ---- the block's extremes at the next trip's first step, published one trip ahead of their use (`trip` already counts
         //      this trip: the next one re-anchors when it is a multiple of kAnchorTrips) ----
         if (ring && (trip % kAnchorTrips) == 0) {
@@ -528,6 +535,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
         if (lane == 0 && misses) atomicAdd(counter + 4, misses);
         if (lane == 0 && staged) atomicAdd(counter + 5, staged);
         if (lane == 0) { atomicAdd(counter + 6, (unsigned long long)n_trips); atomicAdd(counter + 13, (unsigned long long)n_gather_trips); }
+        if (lane == 0 && wave == 0) { atomicAdd(counter + 8, tc_issue); atomicAdd(counter + 9, tc_wait); atomicAdd(counter + 10, tc_barrier); atomicAdd(counter + 11, tc_march); atomicAdd(counter + 12, (unsigned long long)trip); }
     }
 }
 
