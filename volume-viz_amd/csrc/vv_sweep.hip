@@ -111,6 +111,21 @@ __device__ __forceinline__ void lds_pairs(const char *a, const char *b, const ch
 #endif
 }
 
+// One LDS-DMA instruction: lane l copies 16 bytes from its global address to LDS byte address lds_addr + 16 l (lds_addr wave-uniform).
+// Written as inline assembly ON PURPOSE: through __builtin_amdgcn_global_load_lds the compiler knows that an asynchronous write to
+// LDS is in flight and -- it cannot tell which LDS bytes -- puts `s_waitcnt vmcnt(0)` in front of EVERY later ds_read / ds_write /
+// barrier of the wave (seen in the ISA of the first version of this kernel: 7 200 cycles per trip in the copy phase, 4 800 in the
+// march).  That was harmless in round 2's kernel, whose copying waves never touched LDS otherwise, and is fatal here, where every
+// wave both copies and marches.  The ordering the algorithm needs is established explicitly: a counted `s_waitcnt vmcnt(N)`
+// (wait_vm_n) before the trip's barrier.  VMEM operations the compiler does not know about only make ITS counted waits stricter.
+__device__ __forceinline__ void lds_dma16(const void *gptr, const void *lds_ptr)
+{
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)lds_ptr);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gptr), "s"(la) : "memory");
+}
+// the trip's barrier: this wave's LDS writes done, then s_barrier (no `vmcnt(0)`: copies stay in flight across it)
+__device__ __forceinline__ void trip_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 // wait until at most n vector-memory operations of this wave are outstanding (n uniform, 0..kMaxChunks)
 __device__ __forceinline__ void wait_vm_n(int n)
@@ -138,7 +153,7 @@ __device__ __forceinline__ float bits_pos(int b) { return __int_as_float(b) - kP
 // kU: sample steps per trip.  Every step more widens the block's slice window by one sample spacing (two slices on C3) --
 // ring space that is then not in flight --, every step less means a barrier more per sample.
 template <int MAJOR, bool TEX8, bool GRAY, bool INSTR, int kU>
-__global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V,
+__global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
                                                      const float4 *__restrict__ tf,
                                                      const float *__restrict__ rad,
                                                      uint32_t *__restrict__ pixels,
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
     float *lds_tf = (float *)lds;
     Ctl *ctl = (Ctl *)(lds + kTfBytes);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = S.nc;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), NW = S.nc;   // (wave: a scalar for the compiler too)
     const unsigned long long t_blk0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // tile of this block.  Raster order dealt to the XCDs by tile row (block L runs on XCD L % 8 under
     // round-robin dispatch: speed only), or the order the host planned.
@@ -343,14 +358,12 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
                     const uint64_t gstep = (uint64_t)NW * Sr;
                     const int lstep = NW * pitch;
                     for (; rr < nrows; rr += NW) {
-                        if (lane < 8 * ncell)
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
-                                                             (__attribute__((address_space(3))) void *)(lds + lb), 16, 0, 0);
+                        if (lane < 8 * ncell) lds_dma16(gp, lds + lb);
                         gp += gstep; lb += lstep; ++cnt0;
                     }
                 }
                 if (INSTR && wave == 0) staged += (unsigned long long)nrows * pitch;
-                head = pos + np; issued_k = k;
+                head = __builtin_amdgcn_readfirstlane(pos + np); issued_k = k;
             }
             if (INSTR) { const unsigned long long tn = __builtin_readcyclecounter(); tc_issue += tn - tc0; tc0 = tn; }
             int bail = 0;
@@ -366,8 +379,9 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
                 int nwait = 0, acc = cnt0;
 #pragma unroll
                 for (int h = 0; h < kHist; ++h) { if (hiH[h] >= need_hi) nwait = acc; acc += cntH[h]; }
-                wait_vm_n(nwait);
+                wait_vm_n(__builtin_amdgcn_readfirstlane(nwait));             // (a scalar switch, not 64 exec-masked cases)
             }
+            cnt0 = __builtin_amdgcn_readfirstlane(cnt0);
 #pragma unroll
             for (int h = kHist - 1; h > 0; --h) { cntH[h] = cntH[h - 1]; hiH[h] = hiH[h - 1]; }
             cntH[0] = cnt0; hiH[0] = issued_k;
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(FrameParams P, VolumeView V
             const int sw = trip % 3;
             const bool wave_needs = __any(pending && !ert);
             if (!bail && lane == 0 && wave_needs) lds_store_i(&ctl->still[sw], 1);
-            __syncthreads();
+            trip_barrier();
             const int still = __builtin_amdgcn_readfirstlane(lds_load_i(&ctl->still[sw]));
             if (INSTR) { const unsigned long long tn = __builtin_readcyclecounter(); tc_barrier += tn - tc0; tc0 = tn; }
             if (threadIdx.x == 0) lds_store_i(&ctl->still[(trip + 2) % 3], 0);
@@ -663,7 +677,7 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     if (req.steps >= 1 && req.steps <= 2) S.steps = req.steps;
     S.ahead = 6;                             // trips the copies run ahead of the march (as far as the ring has room)
     if (req.ahead >= 0 && req.ahead <= kHist) S.ahead = req.ahead;
-    if (S.wx * S.wy > 16) VV_NO("too many waves");
+    if (S.wx * S.wy > 12) VV_NO("too many waves");
     const bool forced = req.wx >= 1 || req.wy >= 1;
     for (;;) {
         S.nc = S.wx * S.wy;
