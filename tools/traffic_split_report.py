@@ -5,7 +5,7 @@ F plain ones, in order; the plain ones are averaged."""
 import collections, csv, glob, json, os, sys
 
 root = sys.argv[1]
-pat = sys.argv[2] if len(sys.argv) > 2 else "march_"
+pats = (sys.argv[2] if len(sys.argv) > 2 else "march_,sweep_kernel").split(",")
 tim = {}
 if os.path.exists(os.path.join(root, "time.jsonl")):
     for l in open(os.path.join(root, "time.jsonl")):
@@ -16,7 +16,7 @@ counters = collections.OrderedDict()
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        rows += [r for r in csv.DictReader(open(f)) if pat in r["Kernel_Name"] and "rad_kernel" not in r["Kernel_Name"]]
+        rows += [r for r in csv.DictReader(open(f)) if any(p in r["Kernel_Name"] for p in pats) and "rad_kernel" not in r["Kernel_Name"]]
     by = collections.defaultdict(list)
     for r in rows:
         by[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
