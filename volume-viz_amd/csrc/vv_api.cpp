@@ -22,7 +22,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, sweep = -1, sweep_trace = 0, force_big = 0;
-    int skew = -1;
+    int skew = -1, phong_gate = 0;
     int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
@@ -30,7 +30,7 @@ struct vv_knobs {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
-        skew = geti("VV_SKEW", -1);
+        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0);
         sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1);
         sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
@@ -60,6 +60,7 @@ struct vv_context {
     float *d_slice = nullptr; size_t slice_cap = 0;
     float *d_gen = nullptr; size_t gen_cap = 0;       // per-axis tables of the ellipsoid generator
     unsigned long long *d_counter = nullptr;
+    int *d_gate = nullptr;                 // per-CU tickets of the Phong refresh gate (experiment, VV_PHONG_GATE)
     unsigned long long *d_trace = nullptr; int trace_blocks = 0;      // developer trace of the sweep kernel (VV_SWEEP_TRACE=1)
     bool counter_valid = false;
     // streamed upload
@@ -155,6 +156,7 @@ int vv_shutdown(vv_context *c)
     if (c->d_slice) hipFree(c->d_slice);
     if (c->d_gen) hipFree(c->d_gen);
     if (c->d_counter) hipFree(c->d_counter);
+    if (c->d_gate) hipFree(c->d_gate);
     if (c->d_trace) hipFree(c->d_trace);
     for (int i = 0; i < 2; ++i) {
         if (c->pin[i]) hipHostFree(c->pin[i]);
@@ -803,6 +805,11 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (rc) return rc;
     A.rad = c->d_rad; A.rad_out = c->d_rad;
     A.counter = c->d_counter;
+    A.phong_gate = nullptr; A.phong_gate_max = 0;
+    if (K.phong_gate > 0 && shading->phongShading) {
+        if (!c->d_gate) { if (hipMalloc((void **)&c->d_gate, 65536 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); c->d_gate = nullptr; } }
+        if (c->d_gate) { HIPCHK(c, hipMemsetAsync(c->d_gate, 0, 65536 * sizeof(int), st)); A.phong_gate = c->d_gate; A.phong_gate_max = K.phong_gate; }
+    }
 
     const size_t fb = (size_t)W * H * 4;
     uint8_t *d_out = rgba_out;

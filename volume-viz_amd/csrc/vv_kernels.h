@@ -51,6 +51,8 @@ struct MarchArgs {
     uint32_t *pixels;           // device RGBA8 frame
     unsigned long long *counter;
     uint32_t *bricks;
+    int *phong_gate;            // march_phong_kernel: per-CU tickets (65536 ints, zero between launches) or NULL
+    int phong_gate_max;         // blocks of one CU that may be in their refresh (gather) phase at once; 0 = no gate
 };
 
 void launch_rad(const MarchArgs &a, hipStream_t s);

@@ -480,6 +480,13 @@ __global__ __launch_bounds__(256) void march_skew_kernel(FrameParams P, VolumeVi
     }
 }
 
+// index of the CU this wave runs on (XCC, shader engine, shader array, CU): HW_REG_XCC_ID / HW_REG_HW_ID.  Speed only.
+__device__ __forceinline__ int cu_index()
+{
+    const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);       // (size 32, offset 0) of registers 4 and 20
+    return (int)(((xcc & 15u) << 12) | (((hw >> 13) & 7u) << 8) | (((hw >> 12) & 1u) << 7) | ((hw >> 8) & 15u));
+}
+
 // ---------------------------------------------------------------------------
 // march_phong_kernel: one block per reference slab (14x14 interior + apron),
 // 32-deep byte cache in LDS exactly as kernel.cu:125-145 lays it out, but indexed
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
                                                           const float4 *__restrict__ tf, SlabMap M,
                                                           uint32_t *__restrict__ pixels,
                                                           unsigned long long *__restrict__ counter,
-                                                          uint32_t *__restrict__ bricks)
+                                                          uint32_t *__restrict__ bricks, int *__restrict__ gate, int gate_max)
 {
     __shared__ float4 lds_tf[256];
     __shared__ float red[256];
@@ -588,6 +595,7 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
     unsigned long long executed = 0;
     float dist = r.dist0;
     bool ert_done = false;
+    int *gate_slot = nullptr; bool have_ticket = false;
     const bool marching = writer && !skip && !r.cut_return;
     const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
     const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
@@ -624,9 +632,21 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
                 else d = wave_max_i(d);
             }
             if ((threadIdx.x & 63) == 0 && d) atomicMax(&any_live, d);
+            // Refresh gate (experiment, VV_PHONG_GATE=R): at most R blocks of a CU gather at a time, the others shade meanwhile --
+            // the refresh phases of co-resident blocks otherwise thrash the CU's 32 KB L1 against each other.  A ticket per CU in
+            // global memory (blocks of a CU share nothing else); the wait is bounded: after ~50 us the block goes ahead without one.
+            if (gate_max > 0 && threadIdx.x == 0) {
+                gate_slot = gate + cu_index();
+                have_ticket = false;
+                for (int tries = 0; tries < 128; ++tries) {
+                    if (atomicAdd(gate_slot, 1) < gate_max) { have_ticket = true; break; }
+                    atomicSub(gate_slot, 1);
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
             __syncthreads();
             depth = any_live;
-            if (!depth) break;
+            if (!depth) { if (gate_max > 0 && threadIdx.x == 0 && have_ticket) atomicSub(gate_slot, 1); break; }
         }
         // rayMarch: every thread refreshes its 32 cache entries for this chunk  :125-145
         {
@@ -672,6 +692,7 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
             }
         }
         __syncthreads();
+        if (gate_max > 0 && threadIdx.x == 0 && have_ticket) atomicSub(gate_slot, 1);       // every thread's gathers have landed
         if (mine) {
             for (int i = 1; i < kCacheDepth - 1; ++i) {
 #pragma clang fp contract(off)
@@ -770,7 +791,7 @@ static void launch_phong(const MarchArgs &a, hipStream_t s)
     constexpr int BAND = VV_PHONG_BAND;
     dim3 grid((unsigned)(((rows + 8 * BAND - 1) / (8 * BAND)) * 8 * BAND * a.P.nbx));
     hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), (size_t)a.lds_reserve_phong, s,
-                       a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
+                       a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks, a.phong_gate, a.phong_gate_max);
 }
 
 template <int SLICE, int VOXEL, bool TEX8>
