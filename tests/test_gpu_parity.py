@@ -684,47 +684,6 @@ def test_skewed_lock_step_larger_frames(ctx, monkeypatch):
                 assert n_got == n, what
 
 
-@pytest.mark.parametrize("seed", range(0, 48, 2))
-def test_persistent_tile_order_is_bit_identical(ctx, seed, monkeypatch):
-    """march_kernel's persistent, neighbour-aligned tile order (VV_PERSIST = blocks per CU of its grid; speed only): every tile is
-    marched exactly once whatever the cube's screen rectangle says -- cameras inside the cube, cubes partly or wholly off screen,
-    cropped slab rows, every layout: same frames, same sample counts."""
-    monkeypatch.setenv("VV_PERSIST", str(1 + seed % 3))
-    for k, v in ({}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_FORCE_BIG": "1"})[(seed // 2) % 4].items():
-        monkeypatch.setenv(k, v)
-    vol, tf, W, H, cam, sp, _, o = _random_case(seed)
-    ctx.load_volume(vol, tf)
-    for rows in ((0, 0), (1, 3)):
-        if rows[1] > (H + 13) // 14:
-            continue
-        o2 = dict(o); o2["slab_rows"] = rows
-        got = ctx.render(W, H, cam, slice=sp, options=vv.make_options(**o2), fill=0x3C)
-        n_got = ctx.last_sample_count()
-        want, n = O.render(vol, tf, W, H, cam, slice=sp, options=vv.make_options(**o2), fill=0x3C)
-        what = f"persist seed {seed} rows {rows}: {vol.shape} {vol.dtype} {W}x{H}"
-        assert_frames_close(got, want, what)
-        assert n_got == n, what
-
-
-def test_persistent_tile_order_odd_cameras(ctx, monkeypatch):
-    """... and with the cube off centre, partly off screen, behind the eye, and the eye inside it (the rectangle degenerates)."""
-    monkeypatch.setenv("VV_PERSIST", "2")
-    vol = O.noise_u8(40, 48, 36, 9).astype(np.float32) / np.float32(255)
-    tf = vv.transfer_preset(vv.TF_ENGINE)
-    ctx.load_volume(vol, tf)
-    cams = [vv.Camera(origin=(0.0, 0.0, -4.0), look_at=(2.5, 0.3, 0.0)), vv.Camera(origin=(0.0, 0.0, -4.0), look_at=(0.0, -3.0, 0.0)),
-            vv.Camera(origin=(0.2, 0.1, -0.3)), vv.Camera(origin=(0.0, 0.0, -4.0), look_at=(0.0, 0.0, -8.0)),
-            vv.Camera(origin=(3.0, 2.0, 1.0), fov_y=20.0), vv.Camera(origin=(0.0, 0.0, -1.6), fov_y=100.0)]
-    for W, H in ((300, 170), (65, 90)):
-        for cam in cams:
-            o = vv.make_options(step=1 / 64, count_samples=True)
-            got = ctx.render(W, H, cam, options=o, fill=0x77)
-            n_got = ctx.last_sample_count()
-            want, n = O.render(vol, tf, W, H, cam, options=o, fill=0x77)
-            assert_frames_close(got, want, f"persist {W}x{H} {cam.origin} -> {cam.look_at}")
-            assert n_got == n
-
-
 @pytest.mark.parametrize("seed", range(0, 48, 3))
 def test_bricked_copy_is_bit_identical(ctx, seed, monkeypatch):
     """The 4x4x4-brick copy of the volume (used by default for views off the memory axis on volumes

@@ -22,7 +22,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, sweep = -1, sweep_trace = 0, force_big = 0;
-    int skew = -1, phong_gate = 0, persist = -1;
+    int skew = -1, phong_gate = 0;
     int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
@@ -30,7 +30,7 @@ struct vv_knobs {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
-        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0); persist = geti("VV_PERSIST", -1);
+        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0);
         sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1);
         sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
@@ -38,7 +38,7 @@ struct vv_knobs {
 };
 
 struct vv_context {
-    int device = 0, cu_count = 256;
+    int device = 0;
     vv_knobs knobs;
     hipStream_t stream = nullptr;          // used when the caller passes no stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -130,7 +130,6 @@ int vv_init(int device, vv_context **out)
     if (device >= count) return fail(nullptr, VV_ERR_INVALID, "vv_init: device index out of range");
     vv_context *c = new vv_context();
     c->device = device;
-    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) c->cu_count = pr.multiProcessorCount; }
     c->knobs.read();
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
@@ -764,32 +763,6 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         const int ax = sz >= sy ? 2 : 1;
         if (K.skew > 0) A.strips.skew_axis = K.skew <= 2 ? K.skew : ax;
     }
-    // Persistent, neighbour-aligned tile order of march_kernel (speed only; vv_raymarch.hip): as many blocks as stay resident walk the
-    // tiles under the cube's screen rectangle in step with their x-neighbours.  The rectangle is the bounding box of the projected cube
-    // corners (analytic rays; any corner behind the eye: the whole frame); it only orders the work -- every tile is marched either way.
-    A.strips.persist = 0; A.strips.ps0 = 0; A.strips.ps1 = A.strips.n_strips - 1; A.strips.ptx0 = 0; A.strips.ptx1 = (W + 31) / 32 - 1;
-    if (rays->mode == VV_RAYS_ANALYTIC && s_count <= 1 && A.strips.n_strips > 0) {
-        float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
-        bool ok = true;
-        for (int cix = 0; cix < 8 && ok; ++cix) {
-            const float cx = ((cix & 1) ? P.scale[0] : -P.scale[0]) - P.cam_pos[0], cy = ((cix & 2) ? P.scale[1] : -P.scale[1]) - P.cam_pos[1],
-                        cz = ((cix & 4) ? P.scale[2] : -P.scale[2]) - P.cam_pos[2];
-            const float zl = cx * P.look[0] + cy * P.look[1] + cz * P.look[2];
-            if (!(zl > 1e-3f)) { ok = false; break; }
-            const float u = (cx * P.side[0] + cy * P.side[1] + cz * P.side[2]) / (zl * P.tan_half_x), v = (cx * P.up[0] + cy * P.up[1] + cz * P.up[2]) / (zl * P.tan_half_y);
-            const float px = (u + 1.f) * 0.5f * (float)W - 0.5f, py = (v + 1.f) * 0.5f * (float)H - 0.5f;
-            xlo = fminf(xlo, px); xhi = fmaxf(xhi, px); ylo = fminf(ylo, py); yhi = fmaxf(yhi, py);
-        }
-        if (ok && std::isfinite(xlo) && std::isfinite(xhi) && std::isfinite(ylo) && std::isfinite(yhi)) {
-            const int ntx_ = (W + 31) / 32;
-            const int x0 = (int)floorf(fmaxf(xlo - 2.f, 0.f)) / 32, x1 = (int)floorf(fminf(fmaxf(xhi + 2.f, 0.f), (float)(W - 1))) / 32;
-            const int y0s = (int)floorf((fmaxf(ylo - 2.f, (float)A.strips.y0) - (float)A.strips.y0) / 8.f), y1s = (int)floorf((fminf(fmaxf(yhi + 2.f, (float)A.strips.y0), (float)(H - 1)) - (float)A.strips.y0) / 8.f);
-            A.strips.ptx0 = std::max(0, std::min(x0, ntx_ - 1)); A.strips.ptx1 = std::max(A.strips.ptx0, std::min(x1, ntx_ - 1));
-            A.strips.ps0 = std::max(0, std::min(y0s, A.strips.n_strips - 1)); A.strips.ps1 = std::max(A.strips.ps0, std::min(y1s, A.strips.n_strips - 1));
-            if (xhi < -2.f || xlo > (float)W + 2.f || yhi < (float)A.strips.y0 - 2.f) { A.strips.ptx1 = A.strips.ptx0 - 1; }      // the cube is off screen: no rectangle
-        }
-    }
-    A.cu_count = c->cu_count;
     const bool k_unroll = K.unroll >= 1 && K.unroll <= 3, k_reserve = K.lds_reserve >= 0 && K.lds_reserve <= 155 * 1024;
     if (k_unroll) A.unroll = K.unroll;
     if (k_reserve) A.lds_reserve = K.lds_reserve;
@@ -819,13 +792,6 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (K.zpair >= 0) use_zpair = K.zpair != 0 && !use_bricks;
     if (use_zpair) use_zpair = ensure_zpair(c, st);
     if (use_zpair) { A.V.zpair = c->d_zpair; A.V.zp_row_bytes = c->zp_row; A.V.zp_slab_bytes = c->zp_slab; }
-    // (persistent order: VV_PERSIST = blocks per CU of the grid, 0 = off; default below)
-    {
-        int bpc = (int)std::min<size_t>(8, (size_t)163840 / ((size_t)A.lds_reserve + 4096 + 512));
-        if (K.persist >= 0) bpc = std::min(K.persist, 8);
-        else bpc = 0;
-        A.strips.persist = (bpc > 0 && s_count <= 1 && !shading->phongShading) ? bpc : 0;
-    }
     // Phong kernel: 14.3 KB of LDS per block + this reserve.  Measured (tools/ab_phong.sh): volumes up to
     // 1 GiB like 5 blocks per CU (C2 0.54 -> 0.47 ms against no cap, u8 1024^3 1.88 -> 1.78), the 4 GiB
     // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)

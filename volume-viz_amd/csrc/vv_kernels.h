@@ -7,8 +7,7 @@ namespace vv {
 
 // blockIdx.y -> pixel strip (march_kernel) / slab row (march_phong_kernel) of a shard
 struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips, xcd_band;
-                  int skew_axis;      // 0: lock-step march_kernel; 1 / 2: march_skew_kernel, lanes aligned along y / z
-                  int persist, ps0, ps1, ptx0, ptx1; };   // march_kernel: persistent blocks walking the tile rectangle [ps0, ps1] x [ptx0, ptx1] in step
+                  int skew_axis; };   // 0: lock-step march_kernel; 1 / 2: march_skew_kernel, lanes aligned along y / z
 
 struct SlabMap  { int r0, band, band_stride, n_regular; };
 
@@ -40,7 +39,6 @@ struct MarchArgs {
     VolumeView  V;
     int V_type;                 // vv_voxel_type
     bool tex8, gray, phong, instr;
-    int cu_count;               // compute units of the device (grid of the persistent order)
     int lds_reserve;            // march_kernel: dynamic LDS bytes reserved only to cap blocks per CU
     int unroll;                 // march_kernel: samples per loop trip (2 or 3; march_skew_kernel also 1)
     int lds_reserve_phong;      // march_phong_kernel: same occupancy cap (its own LDS is 14 KB)

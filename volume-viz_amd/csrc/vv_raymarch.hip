@@ -14,7 +14,6 @@
 //                     32-deep LDS sample cache.
 #include "vv_device.h"
 #include "vv_kernels.h"
-#include <algorithm>
 
 // This file is compiled four times: as is (linear volume up to 4 GiB), through vv_raymarch_big.hip
 // with VV_BIG_VOLUME (linear, 64-bit slice addressing), through vv_raymarch_brick.hip with
@@ -126,21 +125,28 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ntx = (P.W + 31) >> 5;
-    unsigned long long executed = 0, slots = 0;
+    int strip, tile_x;
+    if (M.xcd_band > 0) {
+        // XCD-aware order (speed only): linear block L runs on XCD L % 8 (round-robin dispatch);
+        // XCD k walks bands k, k+8, ... of xcd_band strips so that neighbouring tiles share an L2
+        const int L = blockIdx.x, per_band = ntx * M.xcd_band;
+        const int xcd = L & 7, j = L >> 3;
+        const int band = (j / per_band) * 8 + xcd, w = j % per_band;
+        strip = band * M.xcd_band + w / ntx; tile_x = w % ntx;
+    } else { strip = blockIdx.x / ntx; tile_x = blockIdx.x % ntx; }
+    // wave tile = 2^tw x 2^(6-tw) pixels; the 4 waves of a block tile a 32x8 strip
     const int tw = M.tile_log2w, th = 6 - tw;
     const int wx = wave & ((32 >> tw) - 1), wy = wave >> (5 - tw);
-    const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
-    const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
-    const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax = P.H >= 2 ? P.H - 2 : 0;
-
-    // ---- one 32 x 8 pixel tile: strip `strip` of the shard, tile `tile_x` of the strip ----
-    auto march_tile = [&](const int strip, const int tile_x) {
     const int x = (tile_x << 5) + (wx << tw) + (lane & ((1 << tw) - 1));
     const int y = M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * 8 + (wy << th) + (lane >> tw);
+    if (strip >= M.n_strips) return;                       // block-uniform, before any barrier
+    stage_tf_planar(lds_tf, tf);
     // pixels the reference never writes: column W-1 / row H-1 (W,H >= 2)
+    const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax = P.H >= 2 ? P.H - 2 : 0;
     const bool in_frame = x <= xmax && y <= ymax && row_owned(P, y);
 
     float res_r = 0.f, res_g = 0.f, res_b = 0.f, res_a = 0.f;
+    unsigned long long executed = 0, slots = 0;
     bool write_zero = false;
 
     Ray r;
@@ -167,6 +173,9 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 
     float dist = r.dist0;
     bool ert = false;
+    const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
+    const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
+
     // chunk loop: kernel.cu:248-278.  All lanes of the wave walk chunks together;
     // a lane whose own `while (dist < upper)` has ended simply has n == 0.
     for (int chunk = 0; chunk < P.max_chunks && __any(dist < r.upper); ++chunk) {
@@ -256,43 +265,6 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
     if (in_frame) {
         if (GRAY) { res_g = res_r; res_b = res_r; }
         pixels[(size_t)y * P.W + x] = write_zero ? 0u : pack_rgba(res_r, res_g, res_b, res_a);
-    }
-    };   // march_tile
-
-    if (!M.persist) {
-        int strip, tile_x;
-        if (M.xcd_band > 0) {
-            // XCD-aware order (speed only): linear block L runs on XCD L % 8 (round-robin dispatch);
-            // XCD k walks bands k, k+8, ... of xcd_band strips so that neighbouring tiles share an L2
-            const int L = blockIdx.x, per_band = ntx * M.xcd_band;
-            const int xcd = L & 7, j = L >> 3;
-            const int band = (j / per_band) * 8 + xcd, w = j % per_band;
-            strip = band * M.xcd_band + w / ntx; tile_x = w % ntx;
-        } else { strip = blockIdx.x / ntx; tile_x = blockIdx.x % ntx; }
-        if (strip >= M.n_strips) return;                   // block-uniform, before any barrier
-        stage_tf_planar(lds_tf, tf);
-        march_tile(strip, tile_x);
-    } else {
-        // Persistent, neighbour-aligned order (speed only; every tile of the shard is marched exactly once whatever the
-        // rectangle says).  The grid is as many blocks as stay resident (8 XCDs x nb): block (xcd, j) walks the tiles of the
-        // rectangle [ps0, ps1] x [ptx0, ptx1] -- the strips of XCD `xcd` only, x fastest -- at positions j, j + nb, ...: blocks
-        // j and j + 1 of an XCD march x-adjacent tiles at the same time in EVERY round, with the same ray lengths, so the
-        // partial 128-byte lines they share meet in the L2 (a block started by the hardware whenever a slot frees does not
-        // keep that relation beyond the first round: profiles/r03_traffic_split.txt).  Then the tiles outside the rectangle
-        // (rays that miss the cube: their pixels are written as zeros, kernel.cu:334-338), dealt round-robin.
-        stage_tf_planar(lds_tf, tf);
-        const int L = blockIdx.x, xcd = L & 7, j = L >> 3, nb = (int)gridDim.x >> 3;
-        const int ncols = M.ptx1 - M.ptx0 + 1;
-        if (ncols > 0 && M.ps1 >= M.ps0) {
-            const int sfirst = M.ps0 + ((xcd - M.ps0) % 8 + 8) % 8;
-            const int nrows = sfirst <= M.ps1 ? (M.ps1 - sfirst) / 8 + 1 : 0;
-            for (int k = j; k < nrows * ncols; k += nb) march_tile(sfirst + 8 * (k / ncols), M.ptx0 + k % ncols);
-        }
-        for (int i = L; i < M.n_strips * ntx; i += (int)gridDim.x) {
-            const int strip = i / ntx, tile_x = i - strip * ntx;
-            if (strip >= M.ps0 && strip <= M.ps1 && tile_x >= M.ptx0 && tile_x <= M.ptx1) continue;     // marched above
-            march_tile(strip, tile_x);
-        }
     }
     if (INSTR) {
         for (int o = 32; o > 0; o >>= 1) executed += __shfl_down(executed, o);
@@ -790,7 +762,6 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
         const int nbands = (a.strips.n_strips + a.strips.xcd_band - 1) / a.strips.xcd_band;
         nblocks = (unsigned)(((nbands + 7) / 8) * 8 * a.strips.xcd_band * ntx);
     }
-    if (a.strips.persist > 0 && !a.strips.skew_axis) nblocks = (unsigned)(std::max(a.cu_count / 8, 1) * 8 * a.strips.persist);   // persist = blocks per CU
     dim3 grid(nblocks);
     // a.lds_reserve bytes of (unused) dynamic LDS cap the number of resident blocks per CU:
     // fewer waves share the 32 KB L1, which this gather kernel needs more than latency hiding
