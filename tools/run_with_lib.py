@@ -4,7 +4,8 @@ round's, built from `git archive <commit>` -- to A/B two rounds on one box.   py
 Entry points the other build lacks are stubbed (calling one raises); everything else goes through the normal binding."""
 import ctypes, os, runpy, sys
 
-lib_path, script, sys.argv[1:] = os.path.abspath(sys.argv[1]), sys.argv[2], sys.argv[2:]
+lib_path, script = os.path.abspath(sys.argv[1]), sys.argv[2]
+sys.argv = sys.argv[2:]
 REPO = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(REPO, "volume-viz_amd", "python")); sys.path.insert(0, REPO)
 import torch  # noqa: F401  (before the first vv_init: INTEGRATION.md)
