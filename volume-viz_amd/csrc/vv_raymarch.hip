@@ -595,7 +595,9 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
     unsigned long long executed = 0;
     float dist = r.dist0;
     bool ert_done = false;
+#ifdef VV_PHONG_GATE_BUILD
     int *gate_slot = nullptr; bool have_ticket = false;
+#endif
     const bool marching = writer && !skip && !r.cut_return;
     const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
     const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
@@ -632,9 +634,10 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
                 else d = wave_max_i(d);
             }
             if ((threadIdx.x & 63) == 0 && d) atomicMax(&any_live, d);
-            // Refresh gate (experiment, VV_PHONG_GATE=R): at most R blocks of a CU gather at a time, the others shade meanwhile --
+            // Refresh gate (experiment build -DVV_PHONG_GATE_BUILD, then VV_PHONG_GATE=R): at most R blocks of a CU gather at a time, the others shade meanwhile --
             // the refresh phases of co-resident blocks otherwise thrash the CU's 32 KB L1 against each other.  A ticket per CU in
             // global memory (blocks of a CU share nothing else); the wait is bounded: after ~50 us the block goes ahead without one.
+#ifdef VV_PHONG_GATE_BUILD
             if (gate_max > 0 && threadIdx.x == 0) {
                 gate_slot = gate + cu_index();
                 have_ticket = false;
@@ -644,9 +647,13 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
                     __builtin_amdgcn_s_sleep(16);
                 }
             }
+#endif
             __syncthreads();
             depth = any_live;
-            if (!depth) { if (gate_max > 0 && threadIdx.x == 0 && have_ticket) atomicSub(gate_slot, 1); break; }
+#ifdef VV_PHONG_GATE_BUILD
+            if (!depth && gate_max > 0 && threadIdx.x == 0 && have_ticket) atomicSub(gate_slot, 1);
+#endif
+            if (!depth) break;
         }
         // rayMarch: every thread refreshes its 32 cache entries for this chunk  :125-145
         {
@@ -692,7 +699,9 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
             }
         }
         __syncthreads();
+#ifdef VV_PHONG_GATE_BUILD
         if (gate_max > 0 && threadIdx.x == 0 && have_ticket) atomicSub(gate_slot, 1);       // every thread's gathers have landed
+#endif
         if (mine) {
             for (int i = 1; i < kCacheDepth - 1; ++i) {
 #pragma clang fp contract(off)
