@@ -308,7 +308,9 @@ int  vv_device_bytes(const vv_context *ctx, unsigned long long out[4]);
 /* ---- metrics (the reference only has a clock() overlay) ---------------- */
 float              vv_last_frame_ms(const vv_context *ctx);      /* hipEvent time of the last vv_render */
 unsigned long long vv_last_sample_count(vv_context *ctx);        /* executed samples, if count_samples */
-int                vv_debug_counters(vv_context *ctx, unsigned long long out[16]);  /* developer statistics of the last instrumented frame */
+int                vv_debug_counters(vv_context *ctx, unsigned long long out[16]);  /* developer statistics of the last instrumented frame; after ANY frame of the
+                                                                                     * opt-in sweep kernel out[7] is valid: bits 0..47 non-zero = the frame is not trustworthy
+                                                                                     * (a synchronous vv_render returns VV_ERR_DEVICE for it by itself) */
 /* developer trace of the sweep kernel's blocks of the last frame rendered with VV_SWEEP_TRACE=1 in the environment:
  * 8 words per block (start, march start, end in 10 ns ticks; hardware ids; tile; slice range; chunks; valid).
  * Returns the number of blocks copied. */

@@ -62,7 +62,7 @@ struct vv_context {
     unsigned long long *d_counter = nullptr;
     int *d_gate = nullptr;                 // per-CU tickets of the Phong refresh gate (experiment, VV_PHONG_GATE)
     unsigned long long *d_trace = nullptr; int trace_blocks = 0;      // developer trace of the sweep kernel (VV_SWEEP_TRACE=1)
-    bool counter_valid = false;
+    bool counter_valid = false, sweep_err_valid = false;   // counters of the last instrumented frame / word 7 of the last sweep frame
     // streamed upload
     hipStream_t copy_stream = nullptr, promo_stream = nullptr;   // H2D copies / u8 -> f32 promotion kernels
     void *pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2] = {nullptr, nullptr}; int pin_next = 0;   // pin_ev[b]: staging buffers b free again
@@ -317,7 +317,7 @@ int vv_device_bytes(const vv_context *c, unsigned long long out[4])
 
 int vv_debug_counters(vv_context *c, unsigned long long out[16])
 {
-    if (!c || !out || !c->counter_valid) return VV_ERR_INVALID;
+    if (!c || !out || (!c->counter_valid && !c->sweep_err_valid)) return VV_ERR_INVALID;
     if (hipEventSynchronize(c->ev1) != hipSuccess) return VV_ERR_DEVICE;
     if (hipMemcpy(out, c->d_counter, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return VV_ERR_DEVICE;
     return VV_OK;
@@ -827,13 +827,14 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (((uintptr_t)d_out & 3) != 0) return fail(c, VV_ERR_INVALID, "vv_render: output buffer must be 4-byte aligned");
 
     if (A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), st));
-    c->counter_valid = A.instr;
+    c->counter_valid = A.instr; c->sweep_err_valid = false;
     HIPCHK(c, hipEventRecord(c->ev0, st));
+    bool sweep_frame = false;
     if (A.phong) {
         if (A.V.bricks) launch_raymarch_bricked(A, st); else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big) launch_raymarch_big(A, st); else launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
-        // Slab sweep (vv_sweep.hip): the volume streamed through LDS by dedicated loader waves.
+        // Slab sweep (vv_sweep.hip): the volume streamed through an LDS slice ring (opt-in).
         bool sweep = false;
         if (K.sweep >= 0) sweep = K.sweep != 0;
         if (sweep) {
@@ -848,7 +849,12 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
             if (!c->d_trace) { if (hipMalloc((void **)&c->d_trace, 8ull * 8 * 65536) != hipSuccess) c->d_trace = nullptr; }
             if (c->d_trace && nb <= 65536) { HIPCHK(c, hipMemsetAsync(c->d_trace, 0, 64ull * nb, st)); A.sweep.trace = c->d_trace; c->trace_blocks = nb; }
         }
-        if (sweep) launch_raymarch_sweep(A, st);
+        if (sweep) {
+            // the kernel reports a clamped footprint / a block that could not be served in counter[7] of EVERY frame, instrumented or not
+            if (!A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter + 7, 0, sizeof(unsigned long long), st));
+            launch_raymarch_sweep(A, st);
+            sweep_frame = true; c->sweep_err_valid = true;
+        }
         else if (A.V.bricks) launch_raymarch_bricked(A, st);
         else if (A.V.zpair) launch_raymarch_zpair(A, st);
         else if (A.V.big) launch_raymarch_big(A, st);
@@ -863,6 +869,13 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         HIPCHK(c, hipStreamSynchronize(st));
     } else if (!stream) {
         HIPCHK(c, hipStreamSynchronize(st));
+    }
+    if (sweep_frame && (!out_on_device || !stream)) {
+        // synchronous call: the frame is complete, so its error word can be looked at (an enqueue-only call cannot; such callers read
+        // vv_debug_counters()[7] after synchronising: bits 0..47 must be zero, bits 48+ count blocks that finished on gathers)
+        unsigned long long e = 0;
+        HIPCHK(c, hipMemcpy(&e, c->d_counter + 7, sizeof e, hipMemcpyDeviceToHost));
+        if (e & 0xFFFFFFFFFFFFull) return fail(c, VV_ERR_DEVICE, "vv_render: the sweep kernel flagged an error (a slice image larger than planned): the frame is not trustworthy; unset VV_SWEEP");
     }
     return VV_OK;
 }
