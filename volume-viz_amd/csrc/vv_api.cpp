@@ -22,7 +22,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, sweep = -1, sweep_trace = 0, force_big = 0;
-    int skew = -1, phong_gate = 0;
+    int skew = -1, phong_gate = 0, block_w = -1;
     int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
@@ -30,7 +30,7 @@ struct vv_knobs {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
-        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0);
+        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0); block_w = geti("VV_BLOCK_W", -1);
         sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1);
         sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
@@ -763,6 +763,16 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         const int ax = sz >= sy ? 2 : 1;
         if (K.skew > 0) A.strips.skew_axis = K.skew <= 2 ? K.skew : ax;
     }
+    // Block shape (speed only): 32 x 8 pixels, or -- 32 x 2 wave tiles only -- 64 x 4 / 128 x 2 (waves side by side: the partial lines two
+    // x-adjacent wave tiles share are then fetched within one block; strips get lower).  VV_BLOCK_W=32/64/128.
+    A.strips.blk_log2w = 5;
+    const int rows_px_8 = A.strips.n_strips * 8;              // (the sweep planner's view of the shard: strips of 8 rows)
+    if (A.strips.tile_log2w == 5 && (K.block_w == 64 || K.block_w == 128)) {
+        A.strips.blk_log2w = K.block_w == 64 ? 6 : 7;
+        const int f = 1 << (A.strips.blk_log2w - 5);          // strips are 8 / f pixels high: f times as many cover the same rows
+        A.strips.n_strips *= f;
+        if (A.strips.strips_per_band < (1 << 26)) A.strips.strips_per_band *= f;
+    }
     const bool k_unroll = K.unroll >= 1 && K.unroll <= 3, k_reserve = K.lds_reserve >= 0 && K.lds_reserve <= 155 * 1024;
     if (k_unroll) A.unroll = K.unroll;
     if (k_reserve) A.lds_reserve = K.lds_reserve;
@@ -838,10 +848,10 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         bool sweep = false;
         if (K.sweep >= 0) sweep = K.sweep != 0;
         if (sweep) {
-            const int own_bands = s_count > 1 ? A.strips.n_strips / A.strips.strips_per_band : 0;
+            const int own_bands = s_count > 1 ? A.strips.n_strips / A.strips.strips_per_band : 0;          // (the ratio does not depend on the strip height)
             A.sweep.wx = K.sw_wx; A.sweep.wy = K.sw_wy; A.sweep.ahead = K.sw_ahead; A.sweep.steps = K.sw_steps;
             A.sweep.verbose = K.sw_verbose;
-            plan_sweep(A, A.strips.y0, A.strips.n_strips * 8, own_bands);
+            plan_sweep(A, A.strips.y0, rows_px_8, own_bands);
             sweep = A.sweep.enabled != 0;
         }
         if (sweep && K.sweep_trace) {

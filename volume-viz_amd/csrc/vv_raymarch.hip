@@ -103,7 +103,7 @@ __device__ __forceinline__ void stage_tf_planar(float *lds_tf, const float4 *__r
 }
 
 // ---------------------------------------------------------------------------
-// march_kernel: no Phong.  blockDim = 256 = 4 waves; a block owns a 32x8 pixel strip, each
+// march_kernel: no Phong.  blockDim = 256 = 4 waves; a block owns a 32x8 pixel strip (64x4 / 128x2 with StripMap::blk_log2w 6 / 7), each
 // wave a 2^tw x 2^(6-tw) tile of it (32x2 when screen x runs along the volume's x axis, so
 // that the lanes of a gather walk one memory row; 8x8 otherwise).  blockIdx.x enumerates
 // (strip, tile) pairs of the shard (StripMap).
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
     __shared__ float lds_tf[1024];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ntx = (P.W + 31) >> 5;
+    const int bl = M.blk_log2w, ntx = (P.W + (1 << bl) - 1) >> bl;        // block = 2^bl x (256 >> bl) pixels
     int strip, tile_x;
     if (M.xcd_band > 0) {
         // XCD-aware order (speed only): linear block L runs on XCD L % 8 (round-robin dispatch);
@@ -136,9 +136,9 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
     } else { strip = blockIdx.x / ntx; tile_x = blockIdx.x % ntx; }
     // wave tile = 2^tw x 2^(6-tw) pixels; the 4 waves of a block tile a 32x8 strip
     const int tw = M.tile_log2w, th = 6 - tw;
-    const int wx = wave & ((32 >> tw) - 1), wy = wave >> (5 - tw);
-    const int x = (tile_x << 5) + (wx << tw) + (lane & ((1 << tw) - 1));
-    const int y = M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * 8 + (wy << th) + (lane >> tw);
+    const int wx = wave & (((1 << bl) >> tw) - 1), wy = wave >> (bl - tw);
+    const int x = (tile_x << bl) + (wx << tw) + (lane & ((1 << tw) - 1));
+    const int y = M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * (256 >> bl) + (wy << th) + (lane >> tw);
     if (strip >= M.n_strips) return;                       // block-uniform, before any barrier
     stage_tf_planar(lds_tf, tf);
     // pixels the reference never writes: column W-1 / row H-1 (W,H >= 2)
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void march_skew_kernel(FrameParams P, VolumeVi
     __shared__ float lds_tf[1024];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ntx = (P.W + 31) >> 5;
+    const int bl = M.blk_log2w, ntx = (P.W + (1 << bl) - 1) >> bl;        // block = 2^bl x (256 >> bl) pixels
     int strip, tile_x;
     if (M.xcd_band > 0) {
         const int L = blockIdx.x, per_band = ntx * M.xcd_band;
@@ -309,9 +309,9 @@ __global__ __launch_bounds__(256) void march_skew_kernel(FrameParams P, VolumeVi
         strip = band * M.xcd_band + w / ntx; tile_x = w % ntx;
     } else { strip = blockIdx.x / ntx; tile_x = blockIdx.x % ntx; }
     const int tw = M.tile_log2w, th = 6 - tw;
-    const int wx = wave & ((32 >> tw) - 1), wy = wave >> (5 - tw);
-    const int x = (tile_x << 5) + (wx << tw) + (lane & ((1 << tw) - 1));
-    const int y = M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * 8 + (wy << th) + (lane >> tw);
+    const int wx = wave & (((1 << bl) >> tw) - 1), wy = wave >> (bl - tw);
+    const int x = (tile_x << bl) + (wx << tw) + (lane & ((1 << tw) - 1));
+    const int y = M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * (256 >> bl) + (wy << th) + (lane >> tw);
     if (strip >= M.n_strips) return;                       // block-uniform, before any barrier
     stage_tf_planar(lds_tf, tf);
     const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax = P.H >= 2 ? P.H - 2 : 0;
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
 template <int SLICE, int VOXEL, bool TEX8, bool GRAY, bool INSTR>
 static void launch_march(const MarchArgs &a, hipStream_t s)
 {
-    const int ntx = (a.P.W + 31) / 32;
+    const int ntx = (a.P.W + (1 << a.strips.blk_log2w) - 1) >> a.strips.blk_log2w;
     unsigned nblocks = (unsigned)(a.strips.n_strips * ntx);
     if (a.strips.xcd_band > 0) {
         const int nbands = (a.strips.n_strips + a.strips.xcd_band - 1) / a.strips.xcd_band;
