@@ -22,7 +22,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, sweep = -1, sweep_trace = 0, force_big = 0;
-    int skew = -1, phong_gate = 0, block_w = -1;
+    int skew = -1, phong_gate = 0, block_w = -1, band_colmajor = 0;
     int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
@@ -30,7 +30,7 @@ struct vv_knobs {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
-        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0); block_w = geti("VV_BLOCK_W", -1);
+        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0); block_w = geti("VV_BLOCK_W", -1); band_colmajor = geti("VV_BAND_COLMAJOR", 0);
         sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1);
         sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
@@ -735,6 +735,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // the tiles that share volume cache lines share an L2 (measured: -4 % on every workload)
     A.strips.xcd_band = 1;
     if (K.xcd_band >= 0 && K.xcd_band <= 64) A.strips.xcd_band = K.xcd_band;
+    A.strips.band_colmajor = K.band_colmajor != 0;
     const bool beyond_caches = c->vol_bytes > (1ull << 30);
     // Sampling density: voxels of volume per sample = (voxels per step) x (voxels per pixel)^2 at the
     // cube centre.  Sparse rays (C3 at 1080p: 4.9) reuse little of a cache line and want few waves on a CU's
@@ -765,10 +766,14 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     }
     // Block shape (speed only): 32 x 8 pixels, or -- 32 x 2 wave tiles only -- 64 x 4 / 128 x 2 (waves side by side: the partial lines two
     // x-adjacent wave tiles share are then fetched within one block; strips get lower).  VV_BLOCK_W=32/64/128.
+    //   measured (tools/ab_env.sh VV_BLOCK_W=64, profiles/r03_block_shape.txt): C3 -2.4 % (EA bytes 1.474 -> 1.364 x algorithmic), u8 1024^3 -1.3 %, tilted views
+    //   -1.7 %, but +4.5 % on C2, +1 % on C1 / 512^3 and +0.5 % on the dense frames of the multi-GPU configurations: used for sparse frames of volumes beyond the caches.
     A.strips.blk_log2w = 5;
     const int rows_px_8 = A.strips.n_strips * 8;              // (the sweep planner's view of the shard: strips of 8 rows)
-    if (A.strips.tile_log2w == 5 && (K.block_w == 64 || K.block_w == 128)) {
-        A.strips.blk_log2w = K.block_w == 64 ? 6 : 7;
+    int block_w = (A.strips.tile_log2w == 5 && beyond_caches && density > 3.5f) ? 64 : 32;
+    if (K.block_w == 32 || K.block_w == 64 || K.block_w == 128) block_w = K.block_w;
+    if (A.strips.tile_log2w == 5 && (block_w == 64 || block_w == 128)) {
+        A.strips.blk_log2w = block_w == 64 ? 6 : 7;
         const int f = 1 << (A.strips.blk_log2w - 5);          // strips are 8 / f pixels high: f times as many cover the same rows
         A.strips.n_strips *= f;
         if (A.strips.strips_per_band < (1 << 26)) A.strips.strips_per_band *= f;
