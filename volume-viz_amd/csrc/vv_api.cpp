@@ -22,7 +22,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, sweep = -1, sweep_trace = 0, force_big = 0;
-    int skew = -1, phong_gate = 0, block_w = -1, band_colmajor = 0;
+    int skew = -1, phong_gate = 0, block_w = -1;
     int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
@@ -30,7 +30,7 @@ struct vv_knobs {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
-        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0); block_w = geti("VV_BLOCK_W", -1); band_colmajor = geti("VV_BAND_COLMAJOR", 0);
+        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0); block_w = geti("VV_BLOCK_W", -1);
         sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1);
         sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
@@ -735,7 +735,6 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // the tiles that share volume cache lines share an L2 (measured: -4 % on every workload)
     A.strips.xcd_band = 1;
     if (K.xcd_band >= 0 && K.xcd_band <= 64) A.strips.xcd_band = K.xcd_band;
-    A.strips.band_colmajor = K.band_colmajor != 0;
     const bool beyond_caches = c->vol_bytes > (1ull << 30);
     // Sampling density: voxels of volume per sample = (voxels per step) x (voxels per pixel)^2 at the
     // cube centre.  Sparse rays (C3 at 1080p: 4.9) reuse little of a cache line and want few waves on a CU's

@@ -132,10 +132,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         const int L = blockIdx.x, per_band = ntx * M.xcd_band;
         const int xcd = L & 7, j = L >> 3;
         const int band = (j / per_band) * 8 + xcd, w = j % per_band;
-        // within a band: strip by strip (x-neighbours are dispatched next to each other), or -- band_colmajor -- column by column
-        // (y-neighbours next to each other, x-neighbours xcd_band apart)
-        if (M.band_colmajor) { strip = band * M.xcd_band + w % M.xcd_band; tile_x = w / M.xcd_band; }
-        else { strip = band * M.xcd_band + w / ntx; tile_x = w % ntx; }
+        strip = band * M.xcd_band + w / ntx; tile_x = w % ntx;
     } else { strip = blockIdx.x / ntx; tile_x = blockIdx.x % ntx; }
     // wave tile = 2^tw x 2^(6-tw) pixels; the 4 waves of a block tile a 32x8 strip
     const int tw = M.tile_log2w, th = 6 - tw;
@@ -309,10 +306,7 @@ __global__ __launch_bounds__(256) void march_skew_kernel(FrameParams P, VolumeVi
         const int L = blockIdx.x, per_band = ntx * M.xcd_band;
         const int xcd = L & 7, j = L >> 3;
         const int band = (j / per_band) * 8 + xcd, w = j % per_band;
-        // within a band: strip by strip (x-neighbours are dispatched next to each other), or -- band_colmajor -- column by column
-        // (y-neighbours next to each other, x-neighbours xcd_band apart)
-        if (M.band_colmajor) { strip = band * M.xcd_band + w % M.xcd_band; tile_x = w / M.xcd_band; }
-        else { strip = band * M.xcd_band + w / ntx; tile_x = w % ntx; }
+        strip = band * M.xcd_band + w / ntx; tile_x = w % ntx;
     } else { strip = blockIdx.x / ntx; tile_x = blockIdx.x % ntx; }
     const int tw = M.tile_log2w, th = 6 - tw;
     const int wx = wave & (((1 << bl) >> tw) - 1), wy = wave >> (bl - tw);
