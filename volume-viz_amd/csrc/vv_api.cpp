@@ -771,7 +771,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     const int rows_px_8 = A.strips.n_strips * 8;              // (the sweep planner's view of the shard: strips of 8 rows)
     int block_w = (A.strips.tile_log2w == 5 && beyond_caches && density > 3.5f) ? 64 : 32;
     if (K.block_w == 32 || K.block_w == 64 || K.block_w == 128) block_w = K.block_w;
-    if (A.strips.tile_log2w == 5 && (block_w == 64 || block_w == 128)) {
+    if ((block_w == 64 || block_w == 128) && (256 / block_w) >= (64 >> A.strips.tile_log2w)) {          // (a block is at least one wave tile high)
         A.strips.blk_log2w = block_w == 64 ? 6 : 7;
         const int f = 1 << (A.strips.blk_log2w - 5);          // strips are 8 / f pixels high: f times as many cover the same rows
         A.strips.n_strips *= f;
