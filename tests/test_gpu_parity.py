@@ -684,6 +684,28 @@ def test_skewed_lock_step_larger_frames(ctx, monkeypatch):
                 assert n_got == n, what
 
 
+@pytest.mark.parametrize("seed", range(0, 48, 2))
+def test_block_shapes_are_bit_identical(ctx, seed, monkeypatch):
+    """march_kernel / march_skew_kernel with the block's four 32 x 2 (or 16 x 4) wave tiles stacked (32 x 8 pixels), 2 x 2 (64 x 4: the policy for sparse
+    frames of big volumes) or side by side (128 x 2); strips are as high as the block.  Forced on the small random cases, whole frames, cropped slab
+    rows and interleaved shards: same frames, same sample counts."""
+    monkeypatch.setenv("VV_BLOCK_W", ("64", "128", "64")[seed % 3])
+    monkeypatch.setenv("VV_TILE_LOG2W", "4" if seed % 6 == 4 else "5")
+    if seed % 8 == 2:
+        monkeypatch.setenv("VV_SKEW", "3")
+    vol, tf, W, H, cam, sp, _, o = _random_case(seed)
+    ctx.load_volume(vol, tf)
+    nby = (H + 13) // 14
+    for extra in ({}, {"slab_rows": (min(1, nby), nby)}, {"shard": (4, 3, seed % 3)}):
+        o2 = dict(o); o2.update(extra)
+        got = ctx.render(W, H, cam, slice=sp, options=vv.make_options(**o2), fill=0x3C)
+        n_got = ctx.last_sample_count()
+        want, n = O.render(vol, tf, W, H, cam, slice=sp, options=vv.make_options(**o2), fill=0x3C)
+        what = f"block shape seed {seed} {extra}: {vol.shape} {vol.dtype} {W}x{H}"
+        assert_frames_close(got, want, what)
+        assert n_got == n, what
+
+
 @pytest.mark.parametrize("seed", range(0, 48, 3))
 def test_bricked_copy_is_bit_identical(ctx, seed, monkeypatch):
     """The 4x4x4-brick copy of the volume (used by default for views off the memory axis on volumes
