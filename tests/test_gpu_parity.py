@@ -687,16 +687,20 @@ def test_skewed_lock_step_larger_frames(ctx, monkeypatch):
 @pytest.mark.parametrize("seed", range(0, 48, 2))
 def test_block_shapes_are_bit_identical(ctx, seed, monkeypatch):
     """march_kernel / march_skew_kernel with the block's four 32 x 2 (or 16 x 4) wave tiles stacked (32 x 8 pixels), 2 x 2 (64 x 4: the policy for sparse
-    frames of big volumes) or side by side (128 x 2); strips are as high as the block.  Forced on the small random cases, whole frames, cropped slab
+    frames of big volumes) or side by side (128 x 2), and its four 8 x 8 tiles 2 x 2 (16 x 16) or stacked (8 x 32) instead of side by side; strips are as high as the block.  Forced on the small random cases, whole frames, cropped slab
     rows and interleaved shards: same frames, same sample counts."""
     monkeypatch.setenv("VV_BLOCK_W", ("64", "128", "64")[seed % 3])
     monkeypatch.setenv("VV_TILE_LOG2W", "4" if seed % 6 == 4 else "5")
     if seed % 8 == 2:
         monkeypatch.setenv("VV_SKEW", "3")
+    elif (seed // 2) % 4 >= 2:        # 8 x 8 wave tiles: 16 x 16 / 8 x 32 blocks (strips higher than 8 rows), linear and bricked
+        monkeypatch.setenv("VV_TILE_LOG2W", "3"); monkeypatch.setenv("VV_BLOCK_W", ("16", "8")[(seed // 8) % 2])
+        if seed % 3 != 1:
+            monkeypatch.setenv("VV_BRICKED", "1")
     vol, tf, W, H, cam, sp, _, o = _random_case(seed)
     ctx.load_volume(vol, tf)
     nby = (H + 13) // 14
-    for extra in ({}, {"slab_rows": (min(1, nby), nby)}, {"shard": (4, 3, seed % 3)}):
+    for extra in ({}, {"slab_rows": (min(1, nby), nby)}, {"shard": (4, 3, seed % 3)}, {"shard": (8, 2, (seed // 2) % 2)}):
         o2 = dict(o); o2.update(extra)
         got = ctx.render(W, H, cam, slice=sp, options=vv.make_options(**o2), fill=0x3C)
         n_got = ctx.last_sample_count()
@@ -924,6 +928,21 @@ def test_c3_headline_frames_match_oracle(ctx):
         assert_frames_close(got, want, f"C3 frame phong={phong} layout={slot}")
         assert n_got == n_want
         assert (got[..., 3] > 0).mean() > 0.3
+        if slot is None and not phong:
+            # the other block shapes on the whole frame: same pixels, same count
+            forms = ({"VV_BLOCK_W": "32"}, {"VV_BLOCK_W": "128"}, {"VV_BLOCK_W": "16", "VV_TILE_LOG2W": "3"}, {"VV_BLOCK_W": "8", "VV_TILE_LOG2W": "3", "VV_BRICKED": "1"})
+            try:
+                for env in forms:
+                    os.environ.update(env); ctx.reread_env()
+                    other = ctx.render(W, H, cam, options=opts)
+                    assert np.array_equal(other, got) and ctx.last_sample_count() == n_got, f"C3 frame under {env}"
+                    for k in env:
+                        os.environ.pop(k)
+            finally:
+                for env in forms:
+                    for k in env:
+                        os.environ.pop(k, None)
+                ctx.reread_env()
     # one rank's share of the 8-GPU frame (BASELINE config C4: 3840x2160, step 1/1024, bands of 4 slab
     # rows dealt round-robin): the shard predicate at full size, rows of other ranks untouched
     W4, H4 = bench.FRAMES[8][0], bench.FRAMES[8][1]

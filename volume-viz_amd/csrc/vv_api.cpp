@@ -763,19 +763,27 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         const int ax = sz >= sy ? 2 : 1;
         if (K.skew > 0) A.strips.skew_axis = K.skew <= 2 ? K.skew : ax;
     }
-    // Block shape (speed only): 32 x 8 pixels, or -- 32 x 2 wave tiles only -- 64 x 4 / 128 x 2 (waves side by side: the partial lines two
-    // x-adjacent wave tiles share are then fetched within one block; strips get lower).  VV_BLOCK_W=32/64/128.
-    //   measured (tools/ab_env.sh VV_BLOCK_W=64, profiles/r03_block_shape.txt): C3 -2.4 % (EA bytes 1.474 -> 1.364 x algorithmic), u8 1024^3 -1.3 %, tilted views
-    //   -1.7 %, but +4.5 % on C2, +1 % on C1 / 512^3 and +0.5 % on the dense frames of the multi-GPU configurations: used for sparse frames of volumes beyond the caches.
+    // Block shape (speed only).  32 x 2 wave tiles: stacked (32 x 8 pixels), 2 x 2 (64 x 4) or side by side (128 x 2): the partial lines two x-adjacent wave
+    // tiles share are then fetched within one block; strips get lower.  8 x 8 wave tiles: side by side (32 x 8), 2 x 2 (16 x 16) or stacked (8 x 32).  VV_BLOCK_W=8...128.
+    //   measured (tools/ab_env.sh, profiles/r03_block_shape.txt): 64 x 4: C3 -2.4 % (EA bytes 1.474 -> 1.364 x algorithmic), u8 1024^3 -1.3 %, tilted views -1.7 %, but
+    //   +4.5 % on C2, +1 % on C1 / 512^3 and +0.5 % on the dense frames of the multi-GPU configurations: used for sparse frames of volumes beyond the caches.
+    //   16 x 16: a strip 16 pixels high re-reads fewer brick layers of its neighbours (which run on other XCDs): rotated C3 -2 % (EA bytes 2.00 -> 1.81 x), C2 -5.5 %,
+    //   C1 -6.5 %, other orbits -2 ... -4 %, 512^3 and the 3840 x 2160 frame -0.5 %: used for every frame with 8 x 8 tiles.
     A.strips.blk_log2w = 5;
     const int rows_px_8 = A.strips.n_strips * 8;              // (the sweep planner's view of the shard: strips of 8 rows)
-    int block_w = (A.strips.tile_log2w == 5 && beyond_caches && density > 3.5f) ? 64 : 32;
-    if (K.block_w == 32 || K.block_w == 64 || K.block_w == 128) block_w = K.block_w;
-    if ((block_w == 64 || block_w == 128) && (256 / block_w) >= (64 >> A.strips.tile_log2w)) {          // (a block is at least one wave tile high)
-        A.strips.blk_log2w = block_w == 64 ? 6 : 7;
-        const int f = 1 << (A.strips.blk_log2w - 5);          // strips are 8 / f pixels high: f times as many cover the same rows
-        A.strips.n_strips *= f;
-        if (A.strips.strips_per_band < (1 << 26)) A.strips.strips_per_band *= f;
+    int block_w = A.strips.tile_log2w == 3 ? 16 : ((A.strips.tile_log2w == 5 && beyond_caches && density > 3.5f) ? 64 : 32);
+    if (K.block_w >= 8 && K.block_w <= 128 && (K.block_w & (K.block_w - 1)) == 0) block_w = K.block_w;
+    {
+        int lw = 3; while ((1 << lw) < block_w) ++lw;
+        const int h = 256 >> lw;                               // strip height in pixels
+        if (lw != 5 && lw >= A.strips.tile_log2w && h >= (64 >> A.strips.tile_log2w)) {     // (a block is at least one wave tile wide and high)
+            A.strips.blk_log2w = lw;
+            // rows past the end of a band or of the range belong to nobody or to another rank: not owned (row_owned), their lanes stay idle
+            if (A.strips.strips_per_band < (1 << 26)) {
+                const int band_px = A.strips.strips_per_band * 8, spb = (band_px + h - 1) / h;
+                A.strips.n_strips = (rows_px_8 / band_px) * spb; A.strips.strips_per_band = spb;
+            } else A.strips.n_strips = (rows_px_8 + h - 1) / h;
+        }
     }
     const bool k_unroll = K.unroll >= 1 && K.unroll <= 3, k_reserve = K.lds_reserve >= 0 && K.lds_reserve <= 155 * 1024;
     if (k_unroll) A.unroll = K.unroll;
