@@ -710,6 +710,40 @@ def test_block_shapes_are_bit_identical(ctx, seed, monkeypatch):
         assert n_got == n, what
 
 
+@pytest.mark.parametrize("seed", range(0, 24))
+def test_tail_chunks_taken_several_at_a_time(ctx, seed, monkeypatch):
+    """march_kernel takes sample 1 of U consecutive chunks in one trip once no lane of the wave has more than one sample per chunk left (rays past the
+    ERT threshold, pin 4).  Frames that are mostly tail: a low threshold, an opaque table, long rays (small steps); every layout, ERT mode and cut
+    plane mode; against the oracle and against the same frame with the batching off (VV_TAIL=0)."""
+    rng = np.random.default_rng(77000 + seed)
+    dims = [(24, 20, 28), (40, 33, 17), (16, 48, 31)][seed % 3]
+    vol = O.noise_u8(*dims, 5 + seed)
+    if seed % 2:
+        vol = vol.astype(np.float32) / np.float32(255)
+    tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
+    tf[:, 3] = rng.uniform(0.2, 1.0, 256).astype(np.float32) if seed % 4 else np.float32(1)
+    if seed % 8 == 5:
+        tf[:, 3] = rng.uniform(0.0, 1.6, 256).astype(np.float32)          # opacities above 1: no tail (every chunk runs the per-sample test)
+    env = [{}, {"VV_ZPAIR": "1"}, {"VV_FORCE_BIG": "1"}, {"VV_BRICKED": "1"}, {"VV_UNROLL": "2"}, {"VV_UNROLL": "1", "VV_FORCE_BIG": "1"}][seed % 6]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cam = vv.Camera.orbit(float(rng.choice([1.2, 2.5, 4.0])), float(rng.uniform(0.3, 2.8)), float(rng.uniform(-3, 3)))
+    st = [vv.SLICE_NONE, vv.SLICE_PLANE, vv.SLICE_PLANE_CUT][seed % 3]
+    sp = vv.make_slice_params(st, (0.5, 0.45, 0.55), (0.3, -0.5, 0.8))
+    o = dict(step=float(rng.choice([1 / 200, 1 / 333, 1 / 97])), ert_threshold=float(rng.choice([0.05, 0.5, 0.9])),
+             ert_mode=vv.ERT_TRUE if seed % 5 == 3 else vv.ERT_REFERENCE, count_samples=True)
+    W, H = int(rng.integers(30, 90)), int(rng.integers(20, 70))
+    ctx.load_volume(vol, tf)
+    got = ctx.render(W, H, cam, slice=sp, options=vv.make_options(**o), fill=0x3C)
+    n_got = ctx.last_sample_count()
+    want, n = O.render(vol, tf, W, H, cam, slice=sp, options=vv.make_options(**o), fill=0x3C)
+    assert_frames_close(got, want, f"tail seed {seed}")
+    assert n_got == n
+    monkeypatch.setenv("VV_TAIL", "0")
+    ctx.reread_env()
+    assert np.array_equal(ctx.render(W, H, cam, slice=sp, options=vv.make_options(**o), fill=0x3C), got) and ctx.last_sample_count() == n_got
+
+
 @pytest.mark.parametrize("seed", range(0, 48, 3))
 def test_bricked_copy_is_bit_identical(ctx, seed, monkeypatch):
     """The 4x4x4-brick copy of the volume (used by default for views off the memory axis on volumes

@@ -22,7 +22,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, sweep = -1, sweep_trace = 0, force_big = 0;
-    int skew = -1, phong_gate = 0, block_w = -1;
+    int skew = -1, phong_gate = 0, block_w = -1, tail = -1;
     int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
@@ -30,7 +30,7 @@ struct vv_knobs {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
-        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0); block_w = geti("VV_BLOCK_W", -1);
+        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0); block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1);
         sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1);
         sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
@@ -770,6 +770,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     //   16 x 16: a strip 16 pixels high re-reads fewer brick layers of its neighbours (which run on other XCDs): rotated C3 -2 % (EA bytes 2.00 -> 1.81 x), C2 -5.5 %,
     //   C1 -6.5 %, other orbits -2 ... -4 %, 512^3 and the 3840 x 2160 frame -0.5 %: used for every frame with 8 x 8 tiles.
     A.strips.blk_log2w = 5;
+    A.strips.tail_batch = K.tail == 0 ? 0 : 1;
     const int rows_px_8 = A.strips.n_strips * 8;              // (the sweep planner's view of the shard: strips of 8 rows)
     int block_w = A.strips.tile_log2w == 3 ? 16 : ((A.strips.tile_log2w == 5 && beyond_caches && density > 3.5f) ? 64 : 32);
     if (K.block_w >= 8 && K.block_w <= 128 && (K.block_w & (K.block_w - 1)) == 0) block_w = K.block_w;

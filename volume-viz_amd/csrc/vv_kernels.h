@@ -8,6 +8,7 @@ namespace vv {
 // blockIdx.y -> pixel strip (march_kernel) / slab row (march_phong_kernel) of a shard
 struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips, xcd_band;
                   int skew_axis;      // 0: lock-step march_kernel; 1 / 2: march_skew_kernel, lanes aligned along y / z
+                  int tail_batch;     // march_kernel: chunks that hold at most one sample per lane (rays past the ERT threshold) are taken U at a time
                   int blk_log2w; };   // a block covers 2^blk_log2w x (256 >> blk_log2w) pixels (5: 32 x 8; 32 x 2 tiles also 64 x 4 / 128 x 2, 8 x 8 tiles 16 x 16 / 8 x 32); strips are that high
 
 struct SlabMap  { int r0, band, band_stride, n_regular; };
