@@ -772,7 +772,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     A.strips.blk_log2w = 5;
     A.strips.tail_batch = K.tail == 0 ? 0 : 1;
     const int rows_px_8 = A.strips.n_strips * 8;              // (the sweep planner's view of the shard: strips of 8 rows)
-    int block_w = A.strips.tile_log2w == 3 ? 16 : ((A.strips.tile_log2w == 5 && beyond_caches && density > 3.5f) ? 64 : 32);
+    int block_w = A.strips.tile_log2w == 3 ? 16 : ((A.strips.tile_log2w == 5 && c->vol_bytes >= (1ull << 30) && density > 3.5f) ? 64 : 32);      // (>=: u8 1024^3 -2 %, tools/policy_sweep.sh)
     if (K.block_w >= 8 && K.block_w <= 128 && (K.block_w & (K.block_w - 1)) == 0) block_w = K.block_w;
     {
         int lw = 3; while ((1 << lw) < block_w) ++lw;
