@@ -856,7 +856,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (A.phong) {
         // (linear volumes beyond the caches take the 64-bit-addressing build even below 4 GiB: the other one is compiled for 5 waves per SIMD, which only
         //  cache-resident volumes want -- 1000^3 f32: 1.884 -> 1.817 ms, tools/ab_env.sh VV_FORCE_BIG=1)
-        if (A.V.bricks) launch_raymarch_bricked(A, st); else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big || beyond_caches) launch_raymarch_big(A, st); else launch_raymarch(A, st);
+        if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); } else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big || beyond_caches) launch_raymarch_big(A, st); else launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
         // Slab sweep (vv_sweep.hip): the volume streamed through an LDS slice ring (opt-in).
@@ -880,7 +880,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
             launch_raymarch_sweep(A, st);
             sweep_frame = true; c->sweep_err_valid = true;
         }
-        else if (A.V.bricks) launch_raymarch_bricked(A, st);
+        else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); }
         else if (A.V.zpair) launch_raymarch_zpair(A, st);
         else if (A.V.big) launch_raymarch_big(A, st);
         else launch_raymarch(A, st);

@@ -61,6 +61,7 @@ void launch_rad(const MarchArgs &a, hipStream_t s);
 void launch_raymarch(const MarchArgs &a, hipStream_t s);
 void launch_raymarch_big(const MarchArgs &a, hipStream_t s);      // same kernels, volumes above 4 GiB
 void launch_raymarch_bricked(const MarchArgs &a, hipStream_t s);  // same kernels on VolumeView::bricks
+void launch_raymarch_bricked_cached(const MarchArgs &a, hipStream_t s);  // ... the build for volumes up to 1 GiB
 void launch_raymarch_zpair(const MarchArgs &a, hipStream_t s);    // same kernels on VolumeView::zpair
 size_t zpair_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *row_bytes, uint32_t *slab_bytes);
 void launch_build_zpair(int vtype, const void *linear, size_t row_pitch, size_t slice_pitch, void *zpair, int nx, int ny, int nz, hipStream_t s);
