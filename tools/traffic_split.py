@@ -28,7 +28,7 @@ import torch
 import volviz_amd as vv
 
 KNOBS = ("VV_XCD_BAND", "VV_LDS_RESERVE", "VV_UNROLL", "VV_TILE_LOG2W", "VV_SWEEP", "VV_SKEW", "VV_RPL", "VV_GATE",
-         "VV_SWEEP_WX", "VV_SWEEP_WY", "VV_SWEEP_AHEAD", "VV_SWEEP_STEPS", "VV_LDS_RESERVE_PHONG", "VV_PHONG_GATE", "VV_BRICKED", "VV_PHONG_DIV", "VV_BLOCK_W", "VV_TAIL")
+         "VV_SWEEP_WX", "VV_SWEEP_WY", "VV_SWEEP_AHEAD", "VV_SWEEP_STEPS", "VV_LDS_RESERVE_PHONG", "VV_PHONG_GATE", "VV_BRICKED", "VV_PHONG_DIV", "VV_BLOCK_W", "VV_TAIL", "VV_PHONG2")
 
 # name, env, slab_rows (None = whole frame), extra
 VARIANTS = [

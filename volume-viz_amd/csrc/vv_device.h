@@ -85,6 +85,8 @@ struct FrameParams {
     int   ert_true;
     int   alpha_unit;             // every table opacity in [0, 1] (a ray past the threshold stays past it)
     int   max_chunks;             // hard bound on the chunk loop (every wave exits)
+    int   safe_div;               // Phong: pixel tangents in [2^-24, 2^8] and steps <= 16, so the gradient's divisions and square root
+                                  // stay far inside the normal range and need no range handling (vv_raymarch_phong2.h)
     // ray source
     int ray_mode, quantize8;
     const uint8_t *front_img, *back_img; int img_w, img_h;
@@ -481,6 +483,14 @@ template <int VOXEL> __device__ __forceinline__ float corner_value(const Corners
 template <int VOXEL> __device__ __forceinline__ float corner_value(const CornersZ &C) { return finish_corners(C); }
 template <int VOXEL> __device__ __forceinline__ float corner_value(const CornersZ8 &C) { return finish_corners(C); }
 
+// ... without the bounds test (the caller applies it)
+template <int VOXEL, class CT>
+__device__ __forceinline__ uint32_t classify_raw(const CT &C)
+{
+    float L = corner_value<VOXEL>(C);
+    float s = (VOXEL == VV_VOXEL_F32) ? L * 255.0f : L;
+    return min((uint32_t)s, 255u);                  // v_cvt_u32_f32 saturates; NaN -> 0
+}
 template <int VOXEL, class CT>
 __device__ __forceinline__ uint32_t classify_index(const CT &C, float px, float py, float pz)
 {
