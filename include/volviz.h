@@ -284,6 +284,16 @@ int  vv_generate_noise_u8(vv_context *ctx, uint8_t *dev_out, int nx, int ny, int
 typedef enum { VV_TF_ENGINE = 0, VV_TF_HEAD = 1, VV_TF_MRI = 2 } vv_tf_preset;
 int  vv_transfer_preset(int preset, float tf_out[1024]);
 
+/* ---- dataset presets: the rule of GLWidget::loadVolume (glwidget.cpp:678-689) ----
+ * The reference picks the transfer table and the object scale from the file name's ending:
+ *     "engine.t3d"  -> g_transferEngine, scale (1, 1, 1)        "head.t3d" -> g_transferEngine, scale (1, 1, 0.8)
+ *     "VisMale.t3d" -> g_transferHead,   scale (1.57, 1, 1)
+ * Returns 1 and fills *tf_preset (a vv_tf_preset) and scale[3] when a rule matches; returns 0 and leaves both
+ * untouched otherwise (the reference then reads an uninitialised table pointer and keeps the previous scale: the
+ * caller's current table and scale are this library's reading of that); VV_ERR_INVALID (< 0) for NULL arguments.
+ * Case-sensitive suffix match, as QString::endsWith. */
+int  vv_dataset_preset(const char *path, int *tf_preset, float scale[3]);
+
 /* ---- .t3d container (volumegenerator.cpp:147-220): 3 x u64 LE header + bytes ---- */
 int  vv_t3d_read_header(const char *path, int header, int *nx, int *ny, int *nz);
 int  vv_t3d_read (const char *path, int header, uint8_t *dst, size_t capacity);

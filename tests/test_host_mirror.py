@@ -98,7 +98,8 @@ def test_paint_loop_symbols():
     """CPU check: the GLWidget-shaped loop (host/paint_loop.h) is part of the mirror library."""
     so = os.path.join(REPO, "volume-viz_amd", "lib", "libvolviz_host.so")
     out = subprocess.check_output(["nm", "-D", "-C", "--defined-only", so]).decode()
-    for name in ("PaintLoop::paintGL()", "PaintLoop::resizeGL(int, int)", "PaintLoop::orbitDrag(int, int)", "PaintLoop::setSliceCanonical(int, float)"):
+    for name in ("PaintLoop::paintGL()", "PaintLoop::resizeGL(int, int)", "PaintLoop::orbitDrag(int, int)", "PaintLoop::setSliceCanonical(int, float)",
+                 "PaintLoop::loadVolume(char const*)"):
         assert name in out, name
 
 
@@ -136,3 +137,46 @@ def test_paint_loop_matches_oracle(tmp_path):
         assert np.array_equal(got, want), f"frame {k}"
         lit += int((got[..., 3] > 0).sum())
     assert lit > 3 * W * H // 20
+
+
+def test_dataset_presets_follow_the_file_name():
+    """GLWidget::loadVolume picks table and scale by the file name's ending (glwidget.cpp:678-689): engine.t3d -> Engine table,
+    (1, 1, 1); head.t3d -> Engine table, (1, 1, 0.8); VisMale.t3d -> Head table, (1.57, 1, 1); anything else: no rule (the
+    caller's table and scale stay).  QString::endsWith is a case-sensitive suffix match."""
+    f32 = lambda *v: tuple(float(np.float32(x)) for x in v)
+    assert vv.dataset_preset("/home/rmartens/shared/cs224textures/engine.t3d") == (vv.TF_ENGINE, f32(1, 1, 1))
+    assert vv.dataset_preset("/home/rmartens/shared/cs224textures/head.t3d") == (vv.TF_ENGINE, f32(1, 1, 0.8))
+    assert vv.dataset_preset("VisMale.t3d") == (vv.TF_HEAD, f32(1.57, 1, 1))
+    assert vv.dataset_preset("my_subhead.t3d") == (vv.TF_ENGINE, f32(1, 1, 0.8))       # a suffix, not a base name
+    for other in ("brain_16.t3d", "HEAD.T3D", "head.t3d.bak", "vismale.t3d", ""):
+        assert vv.dataset_preset(other) is None, other
+
+
+@pytest.mark.gpu
+def test_paint_loop_load_volume(tmp_path):
+    """PaintLoop::loadVolume = GLWidget::loadVolume (glwidget.cpp:668-710): camera back to (0, 0, -4), table and scale from the
+    file name, loadfrom_raw(path, header) -> cudaLoadVolume, dirty, cutting plane dropped.  The committed 16^3 .t3d (written by the
+    compiled reference) is loaded under the name *head.t3d: Engine table, scale (1, 1, 0.8); the frame equals the oracle's."""
+    import shutil
+    demo = os.path.join(REPO, "volume-viz_amd", "bin", "paint_loop_demo")
+    src = os.path.join(REPO, "tests", "golden", "brain_16.t3d")
+    t3d = tmp_path / "mri_head.t3d"
+    shutil.copy(src, t3d)
+    ww, wh = 510, 384
+    r = subprocess.run([demo, str(tmp_path), str(ww), str(wh), str(t3d)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "4 of 5 paints marched" in r.stdout and "preset 0 scale 1 1 0.8" in r.stdout, r.stdout
+    W, H = ww // 3, wh // 3
+    raw = np.fromfile(src, np.uint8)
+    dims = np.frombuffer(raw[:24].tobytes(), "<u8")
+    vol = raw[24:].reshape(int(dims[2]), int(dims[1]), int(dims[0]))
+    cam = vv.Camera(origin=(0.0, 0.0, -4.0), scale=(1.0, 1.0, float(np.float32(0.8))))
+    front = np.fromfile(tmp_path / "front3.rgba", np.uint8).reshape(wh, ww, 4)
+    back = np.fromfile(tmp_path / "back3.rgba", np.uint8).reshape(wh, ww, 4)
+    of, ob = O.first_pass(cam, ww, wh, rays=vv.analytic_rays(cam, aspect=ww / wh))
+    assert np.array_equal(front, of) and np.array_equal(back, ob)
+    got = np.fromfile(tmp_path / "frame3.rgba", np.uint8).reshape(H, W, 4)
+    # Phong stays as the session left it (on); the cross-section does not: hasCuttingPlane = false (:706)
+    want, _ = O.render(vol, O.transfer_preset(vv.TF_ENGINE), W, H, cam, phong=True, rays=vv.image_rays(front, back), fill=0)
+    assert np.array_equal(got, want)
+    assert int((got[..., 3] > 0).sum()) > W * H // 20

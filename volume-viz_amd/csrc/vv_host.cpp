@@ -49,6 +49,26 @@ int vv_transfer_preset(int preset, float tf[1024])
     }
 }
 
+// glwidget.cpp:678-689: table and scale by the file name's ending (QString::endsWith, case-sensitive)
+int vv_dataset_preset(const char *path, int *tf_preset, float scale[3])
+{
+    if (!path || !tf_preset || !scale) return VV_ERR_INVALID;
+    static const struct { const char *suffix; int tf; float s[3]; } rules[] = {
+        {"engine.t3d",  VV_TF_ENGINE, {1.f, 1.f, 1.f}},           // :678-681
+        {"head.t3d",    VV_TF_ENGINE, {1.f, 1.f, 0.8f}},          // :682-685
+        {"VisMale.t3d", VV_TF_HEAD,   {1.57f, 1.f, 1.f}},         // :686-689
+    };
+    const size_t n = strlen(path);
+    for (const auto &r : rules) {
+        const size_t m = strlen(r.suffix);
+        if (n >= m && memcmp(path + n - m, r.suffix, m) == 0) {
+            *tf_preset = r.tf; scale[0] = r.s[0]; scale[1] = r.s[1]; scale[2] = r.s[2];
+            return 1;
+        }
+    }
+    return 0;
+}
+
 // slicewidget.cpp:147-165 with the float algebra of cs123math (REAL == float)
 int vv_slice_matrix(float dx, float dy, float dz, float theta, float phi, float psi, float out[16])
 {

@@ -54,6 +54,33 @@ __device__ __forceinline__ float sqrt_core(float x)
     return s;
 }
 
+// The same two cores on two samples at a time: gfx950 executes v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at two results per
+// lane and cycle, each half rounded exactly like the scalar instruction, so a pair costs 7 + 2 (v_rcp) instead of 16.
+typedef float __attribute__((ext_vector_type(2))) ph_f2;
+__device__ __forceinline__ ph_f2 ph_fma2(ph_f2 a, ph_f2 b, ph_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ ph_f2 div_core2(ph_f2 n, ph_f2 d)
+{
+    const ph_f2 y0 = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)}, one = {1.0f, 1.0f};
+    const ph_f2 e = ph_fma2(-d, y0, one);
+    const ph_f2 y = ph_fma2(e, y0, y0);
+    const ph_f2 q0 = n * y;
+    const ph_f2 r0 = ph_fma2(-d, q0, n);
+    const ph_f2 q1 = ph_fma2(r0, y, q0);
+    const ph_f2 r1 = ph_fma2(-d, q1, n);
+    return ph_fma2(r1, y, q1);
+}
+__device__ __forceinline__ ph_f2 sqrt_core2(ph_f2 x)
+{
+    const ph_f2 s0 = {__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+    const ph_f2 sm = {__uint_as_float(__float_as_uint(s0.x) - 1u), __uint_as_float(__float_as_uint(s0.y) - 1u)};
+    const ph_f2 sp = {__uint_as_float(__float_as_uint(s0.x) + 1u), __uint_as_float(__float_as_uint(s0.y) + 1u)};
+    const ph_f2 t1 = ph_fma2(-sm, s0, x), t2 = ph_fma2(-sp, s0, x);
+    ph_f2 s;
+    s.x = (0.f >= t1.x) ? sm.x : s0.x; s.y = (0.f >= t1.y) ? sm.y : s0.y;
+    s.x = (0.f < t2.x) ? sp.x : s.x;   s.y = (0.f < t2.y) ? sp.y : s.y;
+    return s;
+}
+
 constexpr int kPhRow = 9;                    // dwords per thread and cache plane
 
 // one ray of a thread (a thread marches S of them, one per slab of the block)
@@ -278,22 +305,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 2 ? 2 
                     f_[j] = q255[qf]; a_[j] = q255[qa]; l_[j] = q255[ql]; r_[j] = q255[qr]; t_[j] = q255[qt]; b_[j] = q255[qb];
                 } else { f_[j] = a_[j] = l_[j] = r_[j] = t_[j] = b_[j] = 0.f; }
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            {
 #pragma clang fp contract(off)
-                const int k = 2 * h + j, i = 4 * b + k;
-                vd[k] = (float)i * Q.r.sstep + Q.dist;                            // :254
-                direct[k] = 0.f;
-                if (any_lit[j]) {
-                    const float dx = P.tan_fov_x * vd[k], dy = P.tan_fov_y * vd[k];   // :259-262
-                    float gx = div_core(r_[j] - l_[j], dx), gy = div_core(t_[j] - b_[j], dy), gz = div_core(a_[j] - f_[j], Q.dz2);   // :175-178
-                    if (gx != 0.f && gy != 0.f && gz != 0.f) {                    // :180 (predicated: the lanes that fail keep g)
-                        const float inv = div_core(1.0f, sqrt_core(gx * gx + gy * gy + gz * gz));
-                        gx *= inv; gy *= inv; gz *= inv;
-                    }
-                    float d = (gx * -1.f + gy * -1.f + gz * 1.f) * 0.3f;          // :183
-                    d = fmaxf(0.f, fminf(d, 0.3f));
-                    direct[k] = lit[k] ? d : 0.f;
+                // the two samples k = 2h, 2h + 1 side by side (packed fp32: same roundings as one by one)
+                const int i0 = 4 * b + 2 * h;
+                const ph_f2 fi = {(float)i0, (float)(i0 + 1)}, ss = {Q.r.sstep, Q.r.sstep}, dd = {Q.dist, Q.dist};
+                const ph_f2 vd2 = fi * ss + dd;                                   // :254
+                vd[2 * h] = vd2.x; vd[2 * h + 1] = vd2.y;
+                direct[2 * h] = direct[2 * h + 1] = 0.f;
+                if (any_lit[0] || any_lit[1]) {
+                    const ph_f2 tfx = {P.tan_fov_x, P.tan_fov_x}, tfy = {P.tan_fov_y, P.tan_fov_y}, dz = {Q.dz2, Q.dz2};
+                    const ph_f2 dx = tfx * vd2, dy = tfy * vd2;                   // :259-262
+                    const ph_f2 R2 = {r_[0], r_[1]}, L2 = {l_[0], l_[1]}, T2 = {t_[0], t_[1]}, B2 = {b_[0], b_[1]}, A2 = {a_[0], a_[1]}, F2 = {f_[0], f_[1]};
+                    ph_f2 gx = div_core2(R2 - L2, dx), gy = div_core2(T2 - B2, dy), gz = div_core2(A2 - F2, dz);   // :175-178
+                    const ph_f2 one = {1.0f, 1.0f};
+                    const ph_f2 inv = div_core2(one, sqrt_core2(gx * gx + gy * gy + gz * gz));
+                    const ph_f2 nx = gx * inv, ny = gy * inv, nz = gz * inv;
+                    // :180: normalised only where all three components are non-zero
+                    const bool n0 = gx.x != 0.f && gy.x != 0.f && gz.x != 0.f, n1 = gx.y != 0.f && gy.y != 0.f && gz.y != 0.f;
+                    gx.x = n0 ? nx.x : gx.x; gy.x = n0 ? ny.x : gy.x; gz.x = n0 ? nz.x : gz.x;
+                    gx.y = n1 ? nx.y : gx.y; gy.y = n1 ? ny.y : gy.y; gz.y = n1 ? nz.y : gz.y;
+                    const ph_f2 m1 = {-1.f, -1.f}, c3 = {0.3f, 0.3f};
+                    const ph_f2 d2 = (gx * m1 + gy * m1 + gz * one) * c3;         // :183
+                    direct[2 * h]     = lit[2 * h]     ? fmaxf(0.f, fminf(d2.x, 0.3f)) : 0.f;
+                    direct[2 * h + 1] = lit[2 * h + 1] ? fmaxf(0.f, fminf(d2.y, 0.3f)) : 0.f;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

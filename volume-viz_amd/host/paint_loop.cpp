@@ -20,6 +20,24 @@ PaintLoop::PaintLoop()
     memset(m_cutPoint, 0, sizeof m_cutPoint); memset(m_cutNormal, 0, sizeof m_cutNormal);
 }
 
+void PaintLoop::loadVolume(const char *path)
+{
+    m_pos[0] = 0.f; m_pos[1] = 0.f; m_pos[2] = -4.f;           // :670-671
+    m_look[0] = 0.f; m_look[1] = 0.f; m_look[2] = 4.f;
+    int rc = vv_dataset_preset(path, &m_tfPreset, m_scale);     // :678-689
+    if (rc < 0) die("vv_dataset_preset", rc);
+    float transferFunction[1024];
+    rc = vv_transfer_preset(m_tfPreset, transferFunction);
+    if (rc) die("vv_transfer_preset", rc);
+    VolumeGenerator volgen(0, 0, 0);                            // :674
+    volgen.loadfrom_raw(path, true);                            // :692
+    size_t size;
+    byte *texels = volgen.getBytes(size);                       // :696
+    cudaLoadVolume(texels, size, volgen.getDims(), transferFunction, &volumeArray);   // :700
+    m_renderingDirty = true;                                    // :705-706
+    m_hasCuttingPlane = false;
+}
+
 void PaintLoop::resizeGL(int width, int height)
 {
     m_width = width; m_height = height;

@@ -25,6 +25,14 @@ public:
     // GLWidget::paintGL (glwidget.cpp:188-325).  Returns true when the frame was marched (renderingDirty was set).
     bool paintGL();
 
+    // GLWidget::loadVolume (glwidget.cpp:668-710): camera back to (0, 0, -4) looking at the origin, table and scale by the
+    // file name's ending (vv_dataset_preset; a name no rule matches keeps the current scale and table -- the reference reads an
+    // uninitialised table pointer there -- Engine before any table was chosen), loadfrom_raw(path, header = true) ->
+    // cudaLoadVolume, renderingDirty = true, hasCuttingPlane = false.
+    void loadVolume(const char *path);
+    int transferPreset() const { return m_tfPreset; }
+    const float *scale() const { return m_scale; }
+
     // the setters of the reference's widget that matter to the hot path; each marks the frame dirty (glwidget.cpp:397-460, 743-788)
     void setCameraPosition(float x, float y, float z);                 // position; look re-aimed at the origin
     void orbitDrag(int dx, int dy);                                    // right-button drag, mouseMoveEvent :432-446
@@ -58,6 +66,7 @@ private:
     float m_fovX = 45.f, m_fovY = 45.f;
     bool m_phong = false, m_hasCuttingPlane = false, m_flip = false;
     int m_sliceVis = 0;
+    int m_tfPreset = VV_TF_ENGINE;
     float m_cutPoint[3], m_cutNormal[3];
     std::vector<unsigned char> m_fbo[2], m_resultBuffer, m_resultTexture;
 };

@@ -1,8 +1,9 @@
 // paint_loop_demo.cpp -- drives PaintLoop the way a user drives the reference's 3D view and dumps what it shows:
-//   paint_loop_demo <out_dir> <widget_w> <widget_h>
+//   paint_loop_demo <out_dir> <widget_w> <widget_h> [volume.t3d]
 // frame0: first paint; (second paint without a change: nothing is marched); frame1: after an orbit drag + Phong;
 // frame2: with a coronal cross-section; each with its two first-pass images.  tests/test_host_mirror.py renders the same
-// three frames with the oracle from those images.
+// three frames with the oracle from those images.  With a .t3d path: frame3 after GLWidget::loadVolume(path) (camera reset, table and
+// scale by the file name, cutting plane dropped).
 #include "paint_loop.h"
 #include <cstdio>
 #include <cstdlib>
@@ -18,7 +19,7 @@ static void dump(const std::string &p, const std::vector<unsigned char> &v)
 
 int main(int argc, char **argv)
 {
-    if (argc != 4) return 2;
+    if (argc != 4 && argc != 5) return 2;
     const std::string out = argv[1];
     const int w = atoi(argv[2]), h = atoi(argv[3]);
     initCuda();                                                     // glwidget.cpp:182
@@ -43,7 +44,14 @@ int main(int argc, char **argv)
     gl.setSliceCanonical(CORONAL, 0.1f); gl.setSliceVisualization(2); gl.zoom(60);
     marched += gl.paintGL();
     dump(out + "/frame2.rgba", gl.resultTexture()); dump(out + "/front2.rgba", gl.frontFace()); dump(out + "/back2.rgba", gl.backFace());
-    printf("paint_loop_demo ok: %d x %d widget, render %d x %d, %d of 4 paints marched, last render time %.4f s\n",
-           gl.width(), gl.height(), gl.renderWidth(), gl.renderHeight(), marched, (double)gl.lastRenderTime());
-    return marched == 3 ? 0 : 1;
+    int expected = 3;
+    if (argc == 5) {
+        gl.loadVolume(argv[4]);                                     // window.cpp:347-351 -> glwidget.cpp:668-710
+        marched += gl.paintGL(); ++expected;
+        dump(out + "/frame3.rgba", gl.resultTexture()); dump(out + "/front3.rgba", gl.frontFace()); dump(out + "/back3.rgba", gl.backFace());
+        printf("loadVolume: preset %d scale %g %g %g\n", gl.transferPreset(), (double)gl.scale()[0], (double)gl.scale()[1], (double)gl.scale()[2]);
+    }
+    printf("paint_loop_demo ok: %d x %d widget, render %d x %d, %d of %d paints marched, last render time %.4f s\n",
+           gl.width(), gl.height(), gl.renderWidth(), gl.renderHeight(), marched, expected + 1, (double)gl.lastRenderTime());
+    return marched == expected ? 0 : 1;
 }

@@ -80,7 +80,7 @@ EXPORTS = [
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
     "vv_prepare_layouts", "vv_device_bytes", "vv_debug_sweep_trace", "vv_reread_env", "vv_debug_plan_sweep",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
-    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source",
+    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset",
 ]
 
 _lib = None
@@ -164,6 +164,16 @@ def transfer_preset(preset: int) -> np.ndarray:
     if rc:
         raise VolvizError(rc, "bad preset")
     return tf
+
+
+def dataset_preset(path: str):
+    """vv_dataset_preset: (tf_preset, (sx, sy, sz)) by the file name's ending (glwidget.cpp:678-689), or None."""
+    tfp = C.c_int(-1)
+    sc = (C.c_float * 3)(0, 0, 0)
+    rc = load_library().vv_dataset_preset(path.encode(), C.byref(tfp), sc)
+    if rc < 0:
+        raise VolvizError(rc, "bad argument")
+    return (tfp.value, (sc[0], sc[1], sc[2])) if rc == 1 else None
 
 
 @dataclass
