@@ -6,6 +6,6 @@ CFGS=("--phong --steps 20 --warmup 5" "--config c5 --steps 10 --warmup 3" "--pho
 if [ $# -gt 0 ]; then CFGS=("$@"); fi
 for cfg in "${CFGS[@]}"; do
   line="$cfg |"
-  for v in 0 1 2 0 1 2; do line="$line v$v $(VV_PHONG2=$v run $cfg)"; done
+  for v in ${VERS:-0 1 2 0 1 2}; do line="$line v$v $(VV_PHONG2=$v run $cfg)"; done
   echo "$line"
 done

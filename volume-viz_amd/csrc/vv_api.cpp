@@ -827,7 +827,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // bricked copy likes 5: rotated C3 + Phong 2.25 -> 2.13 ms; C5 5.95 ms with 2, 6.25 with 3, 6.55 with 5)
     A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f && !use_bricks) ? 30000 : 13000);
     if (K.lds_reserve_phong >= 0 && K.lds_reserve_phong <= 146 * 1024) A.lds_reserve_phong = K.lds_reserve_phong;
-    A.phong_v2 = K.phong2 >= 0 ? K.phong2 : 2;          // 0: march_phong_kernel, 1 / 2: march_phong2_kernel with one / two slabs per block
+    A.phong_v2 = K.phong2 > 0 ? K.phong2 : 0;           // 0: march_phong_kernel; 1 / 2 (VV_PHONG2, experimental builds): march_phong2_kernel with one / two slabs per block
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
     int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));

@@ -833,7 +833,9 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
     }
 }
 
-#include "vv_raymarch_phong2.h"
+#ifdef VV_EXPERIMENTAL
+#include "vv_raymarch_phong2.h"      // march_phong2_kernel: the second form of the Phong march (profiles/r04_phong_forms.txt), never faster
+#endif
 
 // ---------------------------------------------------------------------------
 // launchers
@@ -875,17 +877,19 @@ static void launch_phong(const MarchArgs &a, hipStream_t s)
     const int rows = a.slabs.n_regular + 1;                   // grid rows, dealt to the 8 XCDs round-robin
     constexpr int BAND = VV_PHONG_BAND;
     dim3 grid((unsigned)(((rows + 8 * BAND - 1) / (8 * BAND)) * 8 * BAND * a.P.nbx));
+#ifdef VV_EXPERIMENTAL
     if (a.phong_v2 && a.P.safe_div) {       // (frames whose shading divisions would need range handling stay with march_phong_kernel)
         const int S = a.phong_v2 == 2 ? 2 : 1, nbxg = (a.P.nbx + S - 1) / S;
         dim3 grid2((unsigned)(((rows + 7) / 8) * 8 * nbxg));
         if (S == 2)
-            hipLaunchKernelGGL((march_phong2_kernel<SLICE, VOXEL, TEX8, INSTR, 2>), grid2, dim3(256), (size_t)a.lds_reserve_phong, s,
+            hipLaunchKernelGGL((march_phong2_kernel<SLICE, VOXEL, TEX8, INSTR, 2>), grid2, dim3(512), (size_t)a.lds_reserve_phong, s,
                                a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
         else
             hipLaunchKernelGGL((march_phong2_kernel<SLICE, VOXEL, TEX8, INSTR, 1>), grid2, dim3(256), (size_t)a.lds_reserve_phong, s,
                                a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
         return;
     }
+#endif
     hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), (size_t)a.lds_reserve_phong, s,
                        a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks, a.phong_gate, a.phong_gate_max);
 }
