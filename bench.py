@@ -220,11 +220,11 @@ def main():
     vbytes = 4 if args.voxel == "f32" else 1
     rows_owned = len(sharding.owned_rows(H, world, rank))
 
-    def instrumented(camera, phong):
+    def instrumented(camera, phong, rays=None):
         """(executed samples, algorithmic bytes of SURVEY 8d: B_frame) of one frame of this rank"""
         bitmap = torch.zeros((nb * nb * nb + 31) // 32, dtype=torch.int32, device=dev)
         io = vv.make_options(count_samples=True, touched_bricks=bitmap.data_ptr(), **base)
-        ctx.render_device(W, H, camera, frame.data_ptr(), options=io, stream=stream, phong=phong)
+        ctx.render_device(W, H, camera, frame.data_ptr(), options=io, stream=stream, phong=phong, rays=rays)
         torch.cuda.synchronize()
         ns = ctx.last_sample_count()
         words = bitmap.cpu().numpy().view(np.uint32)
@@ -362,13 +362,13 @@ def main():
     # (instrumented, untimed pass) and roofline fraction: the camera off the memory axis (SURVEY 8d's second camera:
     # vv_render samples the bricked copy) and the Phong-shaded frame (march_phong_kernel).
     if world == 1 and args.config == "c3" and args.view == "a" and not args.orbit and not args.phong and not os.environ.get("VV_BENCH_NO_EXTRA"):
-        def timed(camera, phong, reps=20):
+        def timed(camera, phong, reps=20, rays=None):
             for _ in range(60):           # steady state on the other layout / kernel (see the spin-up above)
-                ctx.render_device(W, H, camera, frame.data_ptr(), options=opts, stream=stream, phong=phong)
+                ctx.render_device(W, H, camera, frame.data_ptr(), options=opts, stream=stream, phong=phong, rays=rays)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                ctx.render_device(W, H, camera, frame.data_ptr(), options=opts, stream=stream, phong=phong)
+                ctx.render_device(W, H, camera, frame.data_ptr(), options=opts, stream=stream, phong=phong, rays=rays)
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
@@ -390,6 +390,31 @@ def main():
                                       "frac": round(by_x / (ms_x * 1e-3) / HBM_PEAK, 4), "traffic": tr_x, "algorithmic_bytes_per_launch": int(by_x)}}
             if note_x:
                 out[name]["roofline"]["traffic_note"] = note_x
+
+        # The call the reference's host makes: runCuda marches from the two first-pass images, drawn at three times the render size
+        # (glwidget.cpp:291,358; kernel.cu:317-321).  Images resident in HBM (vv_first_pass on the device), the camera that drew them
+        # passed as the launch-policy hint; the images' sampled texels (8 B per pixel) join the algorithmic bytes.
+        try:
+            iw, ih = 3 * W, 3 * H
+            dfront = torch.empty(ih * iw * 4, dtype=torch.uint8, device=dev); dback = torch.empty_like(dfront)
+            ctx.first_pass_device(iw, ih, cam, dfront.data_ptr(), dback.data_ptr(), stream)
+            irays = vv.device_image_rays(dfront.data_ptr(), dback.data_ptr(), iw, ih, hint=cam)
+            ns_i, by_i = instrumented(cam, False, irays)
+            by_i += 8 * W * rows_owned
+            ms_i = timed(cam, False, rays=irays)
+            ll = ctx.last_launch()
+            ms_q = timed(cam, False, rays=vv.analytic_rays(cam, quantize8=True))     # the same rays without the images: end points rounded to RGBA8
+            out["images_path"] = {"what": f"view a marched from two {iw}x{ih} RGBA8 first-pass images resident in HBM (VV_RAYS_IMAGES, the runCuda-shaped call) with the camera as launch hint",
+                                  "ms_per_frame": round(ms_i, 4), "value": round(ns_i / ms_i / 1e3, 1), "unit": "Msamples/s", "executed_samples_per_frame": int(ns_i),
+                                  "vs_analytic_rays": round(ms_i / (kern_ms if kern_ms > 0 else float("nan")), 4),
+                                  "same_rays_without_images_ms": round(ms_q, 4), "vs_same_rays_without_images": round(ms_i / ms_q, 4),
+                                  "note": "the 8-bit end points of the first-pass contract (firstpass.frag:4) bunch neighbouring rays on a 1/255 grid: that, not the image fetch, is the difference to analytic rays",
+                                  "launch": {k: ll[k] for k in ("tile_log2w", "blk_log2w", "unroll", "lds_reserve", "layout", "view_known")},
+                                  "roofline": {"bound": "hbm", "achieved": round(by_i / (ms_i * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                               "frac": round(by_i / (ms_i * 1e-3) / HBM_PEAK, 4), "traffic": None, "algorithmic_bytes_per_launch": int(by_i)}}
+            del dfront, dback
+        except Exception as e:
+            out["images_path"] = {"error": f"{type(e).__name__}: {e}"}
 
     def cpu_baselines():
         if want_cpu:

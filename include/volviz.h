@@ -117,7 +117,12 @@ typedef struct vv_ray_source {
     int            img_w, img_h;     /* FBO size (reference: widget size = 3x the render size) */
     int            images_on_device; /* 0 = host pointers, 1 = device pointers */
     /* VV_RAYS_ANALYTIC: camera basis (camera.cpp:78-91); eye = camera_params.origin,
-     * projection = perspective(fovY, aspect) as glwidget.cpp:338.             */
+     * projection = perspective(fovY, aspect) as glwidget.cpp:338.
+     * VV_RAYS_IMAGES: optional HINT (speed only, pixels never depend on it): the camera that drew the
+     * images, if the host knows it (glwidget.cpp:188-228 draws them from `camera`).  With a hint vv_render
+     * chooses wave tiles, volume layout and occupancy as for analytic rays; without one it estimates the
+     * view from the images' centre row (host images; device images only in synchronous calls, which may
+     * read them back) and otherwise launches conservatively.  Leave look / up zero for "no hint".      */
     float          look[3];
     float          up[3];
     float          aspect;           /* <= 0 : use W/H */
@@ -318,6 +323,9 @@ int  vv_device_bytes(const vv_context *ctx, unsigned long long out[4]);
 /* ---- metrics (the reference only has a clock() overlay) ---------------- */
 float              vv_last_frame_ms(const vv_context *ctx);      /* hipEvent time of the last vv_render */
 unsigned long long vv_last_sample_count(vv_context *ctx);        /* executed samples, if count_samples */
+int                vv_debug_last_launch(vv_context *ctx, int out[8]);  /* what the launch policy chose for the last vv_render (developer aid): wave tile log2 width,
+                                                                       * block log2 width, samples per trip, LDS reserve, layout (0 linear, 1 linear/64-bit, 2 bricked,
+                                                                       * 3 z-pair), view known to the policy (0 / 1), density x 1000, Phong (0 / 1) */
 int                vv_debug_counters(vv_context *ctx, unsigned long long out[16]);  /* developer statistics of the last instrumented frame; after ANY frame of the
                                                                                      * opt-in sweep kernel out[7] is valid: bits 0..47 non-zero = the frame is not trustworthy
                                                                                      * (a synchronous vv_render returns VV_ERR_DEVICE for it by itself) */

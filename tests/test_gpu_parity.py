@@ -977,6 +977,41 @@ def test_c3_headline_frames_match_oracle(ctx):
                     for k in env:
                         os.environ.pop(k, None)
                 ctx.reread_env()
+    # The call the reference's host makes (runCuda, kernel.cu:388-453): rays from the two first-pass images, FBOs three times the
+    # render size (glwidget.cpp:291,358).  The images are drawn on the device; the frame is marched from them (i) with the camera
+    # as a hint, enqueue-only, (ii) without a hint in a synchronous call, which reads the images' centre row back, (iii) from host
+    # copies.  Each equals the oracle's march over the same images, and each gets the launch the analytic rays get.
+    for cam, want_layout in ((vv.Camera(), 1), (vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5), 2)):
+        ctx.render(W, H, cam, options=vv.make_options(step=1 / 512))
+        ref_launch = ctx.last_launch()
+        assert ref_launch["layout"] == want_layout
+        iw, ih = 3 * W, 3 * H
+        dfront = torch.empty(ih * iw * 4, dtype=torch.uint8, device=dev); dback = torch.empty_like(dfront)
+        ctx.first_pass_device(iw, ih, cam, dfront.data_ptr(), dback.data_ptr())
+        torch.cuda.synchronize()
+        front = dfront.cpu().numpy().reshape(ih, iw, 4); back = dback.cpu().numpy().reshape(ih, iw, 4)
+        want, n_want = O.render(host, tf, W, H, cam, options=vv.make_options(step=1 / 512), rays=vv.image_rays(front, back), threads=threads)
+        opts = vv.make_options(step=1 / 512, count_samples=True)
+        dframe = torch.zeros(H * W, dtype=torch.int32, device=dev)
+        hinted = vv.device_image_rays(dfront.data_ptr(), dback.data_ptr(), iw, ih, hint=cam)
+        ctx.render_device(W, H, cam, dframe.data_ptr(), rays=hinted, options=opts, stream=vv.stream_handle(torch.cuda.current_stream()))
+        torch.cuda.synchronize()
+        got = dframe.cpu().numpy().view(np.uint8).reshape(H, W, 4)
+        assert_frames_close(got, want, "C3 frame from first-pass images (hinted)")
+        assert ctx.last_sample_count() == n_want
+        la = ctx.last_launch()
+        assert {k: la[k] for k in ("tile_log2w", "blk_log2w", "unroll", "lds_reserve", "layout", "view_known")} == \
+               {k: ref_launch[k] for k in ("tile_log2w", "blk_log2w", "unroll", "lds_reserve", "layout", "view_known")}, (la, ref_launch)
+        for name, rs in (("device images, no hint", vv.device_image_rays(dfront.data_ptr(), dback.data_ptr(), iw, ih)), ("host images, no hint", vv.image_rays(front, back))):
+            got = ctx.render(W, H, cam, rays=rs, options=opts)
+            assert_frames_close(got, want, f"C3 frame from first-pass images ({name})")
+            assert ctx.last_sample_count() == n_want
+            la = ctx.last_launch()
+            assert la["view_known"] == 1 and la["tile_log2w"] == ref_launch["tile_log2w"] and la["layout"] == ref_launch["layout"] and \
+                   la["lds_reserve"] == ref_launch["lds_reserve"], (name, la, ref_launch)
+            assert 0.8 < la["density_x1000"] / ref_launch["density_x1000"] < 1.25, (name, la, ref_launch)
+        del dfront, dback, dframe
+        torch.cuda.empty_cache()
     # one rank's share of the 8-GPU frame (BASELINE config C4: 3840x2160, step 1/1024, bands of 4 slab
     # rows dealt round-robin): the shard predicate at full size, rows of other ranks untouched
     W4, H4 = bench.FRAMES[8][0], bench.FRAMES[8][1]

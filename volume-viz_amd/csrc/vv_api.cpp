@@ -14,6 +14,7 @@
 #include <cstring>
 #include <string>
 #include <algorithm>
+#include <vector>
 
 using namespace vv;
 
@@ -59,6 +60,11 @@ struct vv_context {
     uint8_t *d_img = nullptr; size_t img_cap = 0;
     float *d_slice = nullptr; size_t slice_cap = 0;
     float *d_gen = nullptr; size_t gen_cap = 0;       // per-axis tables of the ellipsoid generator
+    // launch-policy estimate taken from device-resident first-pass images (vv_render, synchronous calls), kept while the view stays
+    struct view_key_t { float cam[8]; const void *front, *back; int img_w, img_h, W, H; } view_key;
+    bool view_key_valid = false, view_est_ok = false; float view_side[3] = {0, 0, 0}, view_px_cube = 0.f;
+    std::vector<uint8_t> row_buf;
+    int last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // vv_debug_last_launch
     unsigned long long *d_counter = nullptr;
     int *d_gate = nullptr;                 // per-CU tickets of the Phong refresh gate (experiment, VV_PHONG_GATE)
     unsigned long long *d_trace = nullptr; int trace_blocks = 0;      // developer trace of the sweep kernel (VV_SWEEP_TRACE=1)
@@ -110,6 +116,55 @@ static int ensure(vv_context *c, void **p, size_t *cap, size_t need)
 
 static int finalize_layout(vv_context *c, hipStream_t st);
 static int camera_basis(vv_context *c, FrameParams &P, const camera_params *cam, const vv_ray_source *rays, int W, int H);
+typedef vv_context::view_key_t vv_view_key;
+
+// ---- launch policy for image ray sources (speed only; the pixels never depend on it) ----
+// An image source may carry the camera that drew it in the fields analytic sources use (look, up, aspect): a hint.
+static bool image_source_has_hint(const vv_ray_source *r)
+{
+    if (r->mode != VV_RAYS_IMAGES) return false;
+    const float l2 = r->look[0] * r->look[0] + r->look[1] * r->look[1] + r->look[2] * r->look[2];
+    const float cx = r->look[1] * r->up[2] - r->look[2] * r->up[1], cy = r->look[2] * r->up[0] - r->look[0] * r->up[2], cz = r->look[0] * r->up[1] - r->look[1] * r->up[0];
+    return std::isfinite(l2) && l2 > 0.f && std::isfinite(cx + cy + cz) && (cx * cx + cy * cy + cz * cz) > 0.f;
+}
+static int clamp_row(long long t, int n) { return (int)(t < 0 ? 0 : (t > n - 1 ? n - 1 : t)); }
+static vv_view_key view_key_of(const camera_params *cam, const vv_ray_source *r, int W, int H)
+{
+    vv_view_key k;
+    memset(&k, 0, sizeof k);
+    memcpy(k.cam, cam, sizeof(float) * 8);
+    k.front = r->front; k.back = r->back; k.img_w = r->img_w; k.img_h = r->img_h; k.W = W; k.H = H;
+    return k;
+}
+// The centre pixel row of the frame, looked up in the images exactly as the kernels do (kernel.cu:317-321): where it enters and
+// leaves the cube's silhouette, and how the rays' mid-depth points move through cube space between those pixels.  side = that
+// direction (unit), px_cube = its length per pixel.  False when the row misses the cube.
+static bool estimate_view_from_images(const uint8_t *front, const uint8_t *back, int img_w, int img_h, int W, int H, float side[3], float *px_cube)
+{
+    if (!front || !back || img_w < 1 || img_h < 1 || W < 8 || H < 1) return false;
+    const int y = H / 2;
+    const int ty = clamp_row((long long)floorf((float)y / (float)H * (float)img_h), img_h);
+    const uint8_t *fr = front + (size_t)ty * img_w * 4, *br = back + (size_t)ty * img_w * 4;
+    auto texel = [&](int x) { return clamp_row((long long)floorf((float)x / (float)W * (float)img_w), img_w); };
+    auto hit = [&](int x) { const int t = texel(x) * 4; return fr[t] != br[t] || fr[t + 1] != br[t + 1] || fr[t + 2] != br[t + 2]; };
+    int xl = -1, xr = -1;
+    for (int x = 0; x <= W - 2; ++x) if (hit(x)) { xl = x; break; }
+    if (xl < 0) return false;
+    for (int x = W - 2; x >= xl; --x) if (hit(x)) { xr = x; break; }
+    if (xr - xl < 8) return false;
+    const int a = (xl + xr) / 2 - (xr - xl) / 8, b = (xl + xr) / 2 + (xr - xl) / 8;   // the middle quarter: rays that cross the cube front to back
+    float d[3], len2 = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        const int ta = texel(a) * 4 + k, tb = texel(b) * 4 + k;
+        d[k] = (((float)fr[tb] + (float)br[tb]) - ((float)fr[ta] + (float)br[ta])) / (2.f * 255.f);
+        len2 += d[k] * d[k];
+    }
+    if (!(len2 > 0.f)) return false;
+    const float len = sqrtf(len2);
+    side[0] = d[0] / len; side[1] = d[1] / len; side[2] = d[2] / len;
+    *px_cube = len / (float)(b - a);
+    return true;
+}
 static bool ensure_bricks(vv_context *c, hipStream_t st);
 static bool ensure_zpair(vv_context *c, hipStream_t st);
 
@@ -703,19 +758,60 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
                      P.step[0] <= 16.f && P.step[1] <= 16.f && P.step[2] <= 16.f;          // (>= 1e-5 and finite: checked above)
     }
     P.ray_mode = rays->mode; P.quantize8 = rays->quantize8;
+    // What the launch policy below knows about the view (speed only): the camera basis -- given (analytic rays), hinted (an image
+    // source whose look / up fields are filled in: the host that drew the first pass knows its camera) or estimated from the images.
+    bool have_basis = false;
+    float density = 1e9f;                           // voxels of volume per sample; unknown ray source: treat as sparse
     if (rays->mode == VV_RAYS_ANALYTIC) {
         int brc = camera_basis(c, P, cam, rays, W, H);
         if (brc) return brc;
+        have_basis = true;
     } else {
+        if (image_source_has_hint(rays)) have_basis = camera_basis(nullptr, P, cam, rays, W, H) == VV_OK;
         const size_t ib = (size_t)rays->img_w * rays->img_h * 4;
         P.img_w = rays->img_w; P.img_h = rays->img_h;
-        if (rays->images_on_device) { P.front_img = rays->front; P.back_img = rays->back; }
+        if (rays->images_on_device) {
+            if (((uintptr_t)rays->front & 3) || ((uintptr_t)rays->back & 3)) return fail(c, VV_ERR_INVALID, "vv_render: device images must be 4-byte aligned");
+            P.front_img = rays->front; P.back_img = rays->back;
+        }
         else {
             int rc = ensure(c, (void **)&c->d_img, &c->img_cap, 2 * ib);
             if (rc) return rc;
             HIPCHK(c, hipMemcpyAsync(c->d_img, rays->front, ib, hipMemcpyHostToDevice, st));
             HIPCHK(c, hipMemcpyAsync(c->d_img + ib, rays->back, ib, hipMemcpyHostToDevice, st));
             P.front_img = c->d_img; P.back_img = c->d_img + ib;
+        }
+        // no hint: the images themselves say how screen x runs through the volume and how dense the rays are.  Host images are
+        // read in place; device images only by a synchronous call (an enqueue-only call must not wait for the stream), and the
+        // estimate is kept while camera and image geometry stay the same.
+        if (!have_basis) {
+            bool est = false;
+            float side[3] = {0, 0, 0}, px_cube = 0.f;
+            if (!rays->images_on_device) est = estimate_view_from_images(rays->front, rays->back, rays->img_w, rays->img_h, W, H, side, &px_cube);
+            else if (!stream) {
+                const vv_view_key key = view_key_of(cam, rays, W, H);
+                if (c->view_key_valid && memcmp(&c->view_key, &key, sizeof key) == 0) { est = c->view_est_ok; memcpy(side, c->view_side, sizeof side); px_cube = c->view_px_cube; }
+                else {
+                    const int yt = clamp_row((H / 2) * (long long)rays->img_h / H, rays->img_h);
+                    const size_t rowb = (size_t)rays->img_w * 4;
+                    c->row_buf.resize(2 * rowb);
+                    HIPCHK(c, hipStreamSynchronize(st));
+                    HIPCHK(c, hipMemcpy(c->row_buf.data(), rays->front + (size_t)yt * rowb, rowb, hipMemcpyDeviceToHost));
+                    HIPCHK(c, hipMemcpy(c->row_buf.data() + rowb, rays->back + (size_t)yt * rowb, rowb, hipMemcpyDeviceToHost));
+                    // (the centre row alone, presented as a one-row image pair)
+                    est = estimate_view_from_images(c->row_buf.data(), c->row_buf.data() + rowb, rays->img_w, 1, W, 1, side, &px_cube);
+                    c->view_key = key; c->view_key_valid = true; c->view_est_ok = est; memcpy(c->view_side, side, sizeof side); c->view_px_cube = px_cube;
+                }
+            }
+            if (est) {
+                P.side[0] = side[0]; P.side[1] = side[1]; P.side[2] = side[2];
+                have_basis = true;
+                // px_cube = cube-space distance between horizontally neighbouring pixels' rays at mid depth
+                const float vpw = cbrtf((float)c->nx * (float)c->ny * (float)c->nz);
+                const float px_vox = px_cube * vpw;
+                const float step_vox = fmaxf(P.step[0] * c->nx, fmaxf(P.step[1] * c->ny, P.step[2] * c->nz));
+                if (std::isfinite(px_vox) && px_vox > 0.f && step_vox > 0.f) density = step_vox * px_vox * px_vox;
+            }
         }
     }
     A.V = view_of(c); A.V_type = c->vtype;
@@ -724,7 +820,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // or two cache lines (measured C3, view along z: 1.6 ms vs 2.1 ms for 8x8); otherwise the
     // compact 8x8 tile touches the fewest lines.  VV_TILE_LOG2W overrides (3, 4 or 5).
     A.strips.tile_log2w = 3;
-    if (rays->mode == VV_RAYS_ANALYTIC) {
+    if (have_basis) {
         const float ax = fabsf(P.side[0]) , ay = fabsf(P.side[1]), az = fabsf(P.side[2]);
         if (ax >= 0.97f * sqrtf(ax * ax + ay * ay + az * az)) A.strips.tile_log2w = 5;
     }
@@ -746,8 +842,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // L1; the denser frames of the multi-GPU configurations (2716x1528: 2.5, 3840x2160: 1.2, and 0.6 at
     // step 1/1024) want more: the whole 3840x2160 / 1024-step frame takes 3.51 ms with 2 blocks per CU and
     // 2.71 ms with 4 (tools/sweep.sh --frame-of 8; bricked copy 4.71 -> 3.34 ms, Phong 9.0 -> 7.9 ms).
-    float density = 1e9f;                           // unknown ray source: treat as sparse
-    if (rays->mode == VV_RAYS_ANALYTIC && H > 0) {
+    if ((rays->mode == VV_RAYS_ANALYTIC || image_source_has_hint(rays)) && have_basis && H > 0) {
         const float dist = vlen_h(cam->origin[0], cam->origin[1], cam->origin[2]);
         const float vpw = cbrtf(((float)c->nx / (2.f * P.scale[0])) * ((float)c->ny / (2.f * P.scale[1])) * ((float)c->nz / (2.f * P.scale[2])));
         const float px_vox = 2.f * P.tan_half_y * dist / (float)H * vpw;
@@ -857,6 +952,12 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
 
     if (A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), st));
     c->counter_valid = A.instr; c->sweep_err_valid = false;
+    {
+        const int layout = A.V.bricks ? 2 : (A.V.zpair ? 3 : ((A.V.big || (A.phong && beyond_caches)) ? 1 : 0));
+        const int v[8] = {A.strips.tile_log2w, A.strips.blk_log2w, A.unroll, A.phong ? A.lds_reserve_phong : A.lds_reserve, layout, have_basis ? 1 : 0,
+                          (int)fminf(density * 1000.f, 2e9f), A.phong ? 1 : 0};
+        memcpy(c->last_launch, v, sizeof v);
+    }
     HIPCHK(c, hipEventRecord(c->ev0, st));
     bool sweep_frame = false;
     if (A.phong) {
@@ -943,6 +1044,15 @@ int vv_first_pass(vv_context *c, int W, int H, const camera_params *cam, const v
         HIPCHK(c, hipMemcpyAsync(back, db, ib, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
     } else if (!stream) HIPCHK(c, hipStreamSynchronize(st));
+    return VV_OK;
+}
+
+// what vv_render chose for its last frame (developer aid, tests): {wave tile log2 width, block log2 width, samples per trip, LDS reserve,
+// layout (0 linear, 1 linear with 64-bit addressing, 2 bricked, 3 z-pair), 1 if the view was known to the policy, density x 1000, Phong}
+int vv_debug_last_launch(vv_context *c, int out[8])
+{
+    if (!c || !out) return VV_ERR_INVALID;
+    memcpy(out, c->last_launch, sizeof c->last_launch);
     return VV_OK;
 }
 

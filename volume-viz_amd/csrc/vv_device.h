@@ -121,10 +121,11 @@ __device__ __forceinline__ void ray_endpoints(const FrameParams &P, int x, int y
         float u = (float)x / (float)P.W, v = (float)y / (float)P.H;
         int tx = (int)floorf(u * (float)P.img_w), ty = (int)floorf(v * (float)P.img_h);
         tx = max(0, min(tx, P.img_w - 1)); ty = max(0, min(ty, P.img_h - 1));
-        const uint8_t *f = P.front_img + 4 * ((size_t)ty * P.img_w + tx);
-        const uint8_t *b = P.back_img  + 4 * ((size_t)ty * P.img_w + tx);
-        front = mk3(f[0] / 255.f, f[1] / 255.f, f[2] / 255.f);
-        back  = mk3(b[0] / 255.f, b[1] / 255.f, b[2] / 255.f);
+        // one dword per texel (the images are 4-byte aligned: vv_render checks)
+        const size_t t = (size_t)ty * P.img_w + tx;
+        const uint32_t f = ((const uint32_t *)P.front_img)[t], b = ((const uint32_t *)P.back_img)[t];
+        front = mk3((float)(f & 255u) / 255.f, (float)((f >> 8) & 255u) / 255.f, (float)((f >> 16) & 255u) / 255.f);
+        back  = mk3((float)(b & 255u) / 255.f, (float)((b >> 8) & 255u) / 255.f, (float)((b >> 16) & 255u) / 255.f);
         return;
     }
     float ndx = (2.0f * ((float)x + 0.5f)) / (float)P.W - 1.0f;

@@ -80,7 +80,7 @@ EXPORTS = [
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
     "vv_prepare_layouts", "vv_device_bytes", "vv_debug_sweep_trace", "vv_reread_env", "vv_debug_plan_sweep",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
-    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset",
+    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset", "vv_debug_last_launch",
 ]
 
 _lib = None
@@ -121,6 +121,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_promote_u8_to_f32.argtypes = [vp, vp, vp, sz, vp]
     lib.vv_generate_noise_u8.argtypes = [vp, vp, i, i, i, C.c_uint32, vp]
     lib.vv_transfer_preset.argtypes = [i, vp]
+    lib.vv_dataset_preset.argtypes = [C.c_char_p, vp, vp]
     lib.vv_t3d_read_header.argtypes = [C.c_char_p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     lib.vv_t3d_read.argtypes = [C.c_char_p, i, vp, sz]
     lib.vv_t3d_write.argtypes = [C.c_char_p, i, vp, i, i, i]
@@ -136,6 +137,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_cut_plane_from_drag.argtypes = [vp, vp, vp, f, vp, vp, vp, vp, vp, vp]
     lib.vv_cut_plane_drag.argtypes = [vp, vp, vp, i, i, i, i]
     lib.vv_debug_counters.argtypes = [vp, vp]
+    lib.vv_debug_last_launch.argtypes = [vp, vp]
     lib.vv_debug_sweep_trace.argtypes = [vp, vp, i]
     lib.vv_reread_env.argtypes = [vp]
     lib.vv_debug_plan_sweep.argtypes = [i, i, C.POINTER(camera_params), C.POINTER(vv_ray_source), C.POINTER(f * 3), i, i, i, i, i, i, vp]
@@ -230,7 +232,15 @@ def analytic_rays(cam: Camera, quantize8: bool = False, aspect: float = 0.0) -> 
     return rs
 
 
-def image_rays(front: np.ndarray, back: np.ndarray) -> vv_ray_source:
+def _hint(rs: vv_ray_source, cam: Optional["Camera"], aspect: float) -> vv_ray_source:
+    if cam is not None:                     # the camera that drew the images: a launch-policy hint (include/volviz.h)
+        rs.look[:] = cam.look()
+        rs.up[:] = [float(v) for v in cam.up]
+        rs.aspect = aspect
+    return rs
+
+
+def image_rays(front: np.ndarray, back: np.ndarray, hint: Optional["Camera"] = None, aspect: float = 0.0) -> vv_ray_source:
     """front/back: uint8 [H_fbo, W_fbo, 4] host arrays (kept alive by the caller)."""
     assert front.dtype == np.uint8 and back.dtype == np.uint8 and front.shape == back.shape
     rs = vv_ray_source()
@@ -239,7 +249,18 @@ def image_rays(front: np.ndarray, back: np.ndarray) -> vv_ray_source:
     rs.back = back.ctypes.data
     rs.img_h, rs.img_w = front.shape[0], front.shape[1]
     rs.images_on_device = 0
-    return rs
+    return _hint(rs, hint, aspect)
+
+
+def device_image_rays(front_ptr: int, back_ptr: int, img_w: int, img_h: int, hint: Optional["Camera"] = None, aspect: float = 0.0) -> vv_ray_source:
+    """Two device-resident RGBA8 images (e.g. written by Context.first_pass_device)."""
+    rs = vv_ray_source()
+    rs.mode = RAYS_IMAGES
+    rs.front = front_ptr
+    rs.back = back_ptr
+    rs.img_h, rs.img_w = img_h, img_w
+    rs.images_on_device = 1
+    return _hint(rs, hint, aspect)
 
 
 def make_slice_params(slice_type: int = SLICE_NONE, point=(0.5, 0.5, 0.5), normal=(0.0, 0.0, 1.0)) -> slice_params:
@@ -369,6 +390,11 @@ class Context:
         self._chk(self.lib.vv_first_pass(self.h, img_w, img_h, C.byref(cp), C.byref(rs), front.ctypes.data, back.ctypes.data, 0, None))
         return front, back
 
+    def first_pass_device(self, img_w: int, img_h: int, cam: Camera, front_ptr: int, back_ptr: int, stream: int = 0):
+        """vv_first_pass into two device buffers of img_w * img_h * 4 bytes, enqueued on `stream`."""
+        cp = cam.params(img_w, img_h); rs = analytic_rays(cam)
+        self._chk(self.lib.vv_first_pass(self.h, img_w, img_h, C.byref(cp), C.byref(rs), front_ptr, back_ptr, 1, stream))
+
     def last_frame_ms(self) -> float:
         return float(self.lib.vv_last_frame_ms(self.h))
 
@@ -376,6 +402,13 @@ class Context:
         out = np.zeros(16, np.uint64)
         self._chk(self.lib.vv_debug_counters(self.h, out.ctypes.data))
         return out
+
+    def last_launch(self) -> dict:
+        """vv_debug_last_launch: what the launch policy chose for the last render."""
+        out = (C.c_int * 8)()
+        self._chk(self.lib.vv_debug_last_launch(self.h, out))
+        k = ("tile_log2w", "blk_log2w", "unroll", "lds_reserve", "layout", "view_known", "density_x1000", "phong")
+        return dict(zip(k, list(out)))
 
     def reread_env(self):
         """vv_reread_env: pick up VV_* knobs changed since the last volume load."""
