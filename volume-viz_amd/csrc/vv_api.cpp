@@ -1151,6 +1151,8 @@ static int generate_impl(vv_context *c, uint8_t *out, int out_on_device, int nx,
     if (!c) return fail(nullptr, VV_ERR_INVALID, "vv_generate_ellipsoids: NULL context");
     if (!out || nx < 1 || ny < 1 || nz < 1 || n < 0 || n > kMaxEllipsoids || (n > 0 && (!centers || !axes || !colors)))
         return fail(c, VV_ERR_INVALID, "vv_generate_ellipsoids: bad argument (n <= 64)");
+    if ((((unsigned long long)nx + 15ull) / 16ull) * (unsigned long long)ny >= (1ull << 31))
+        return fail(c, VV_ERR_INVALID, "vv_generate_ellipsoids: a slice must have fewer than 2^31 16-voxel chunks");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = pick_stream(c, stream);
     const size_t bytes = (size_t)nx * ny * nz;
