@@ -323,6 +323,8 @@ int  vv_device_bytes(const vv_context *ctx, unsigned long long out[4]);
 /* ---- metrics (the reference only has a clock() overlay) ---------------- */
 float              vv_last_frame_ms(const vv_context *ctx);      /* hipEvent time of the last vv_render */
 unsigned long long vv_last_sample_count(vv_context *ctx);        /* executed samples, if count_samples */
+int                vv_build_is_experimental(void);   /* 0: the product library; 1: libvolviz_hip_x.so, built with -DVV_EXPERIMENTAL, which adds the opt-in kernels
+                                                      * behind VV_SKEW / VV_SWEEP / VV_PHONG2 (bit-identical, never faster; volume-viz_amd/Makefile) */
 int                vv_debug_last_launch(vv_context *ctx, int out[8]);  /* what the launch policy chose for the last vv_render (developer aid): wave tile log2 width,
                                                                        * block log2 width, samples per trip, LDS reserve, layout (0 linear, 1 linear/64-bit, 2 bricked,
                                                                        * 3 z-pair), view known to the policy (0 / 1), density x 1000, Phong (0 / 1) */

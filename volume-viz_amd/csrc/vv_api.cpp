@@ -23,7 +23,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, sweep = -1, sweep_trace = 0, force_big = 0;
-    int skew = -1, phong_gate = 0, block_w = -1, tail = -1, phong2 = -1;
+    int skew = -1, block_w = -1, tail = -1, phong2 = -1;
     int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
@@ -31,7 +31,7 @@ struct vv_knobs {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
-        skew = geti("VV_SKEW", -1); phong_gate = geti("VV_PHONG_GATE", 0); block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1); phong2 = geti("VV_PHONG2", -1);
+        skew = geti("VV_SKEW", -1); block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1); phong2 = geti("VV_PHONG2", -1);
         sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1);
         sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
@@ -66,7 +66,6 @@ struct vv_context {
     std::vector<uint8_t> row_buf;
     int last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // vv_debug_last_launch
     unsigned long long *d_counter = nullptr;
-    int *d_gate = nullptr;                 // per-CU tickets of the Phong refresh gate (experiment, VV_PHONG_GATE)
     unsigned long long *d_trace = nullptr; int trace_blocks = 0;      // developer trace of the sweep kernel (VV_SWEEP_TRACE=1)
     bool counter_valid = false, sweep_err_valid = false;   // counters of the last instrumented frame / word 7 of the last sweep frame
     // streamed upload
@@ -211,7 +210,6 @@ int vv_shutdown(vv_context *c)
     if (c->d_slice) hipFree(c->d_slice);
     if (c->d_gen) hipFree(c->d_gen);
     if (c->d_counter) hipFree(c->d_counter);
-    if (c->d_gate) hipFree(c->d_gate);
     if (c->d_trace) hipFree(c->d_trace);
     for (int i = 0; i < 2; ++i) {
         if (c->pin[i]) hipHostFree(c->pin[i]);
@@ -314,6 +312,10 @@ int vv_prepare_layouts(vv_context *c, int which, void *stream)
 int vv_debug_plan_sweep(int W, int H, const camera_params *cam, const vv_ray_source *rays, const float step[3],
                         int voxel_type, int nx, int ny, int nz, int phong, int slice_type, int out[12])
 {
+#ifndef VV_EXPERIMENTAL
+    (void)W; (void)H; (void)cam; (void)rays; (void)step; (void)voxel_type; (void)nx; (void)ny; (void)nz; (void)phong; (void)slice_type; (void)out;
+    return fail(nullptr, VV_ERR_INVALID, "vv_debug_plan_sweep: the sweep kernel is only part of the experimental build (libvolviz_hip_x.so)");
+#else
     if (!cam || !rays || !step || !out || W < 1 || H < 1 || nx < 1 || ny < 1 || nz < 1) return VV_ERR_INVALID;
     MarchArgs A;
     memset(&A, 0, sizeof A);
@@ -341,6 +343,17 @@ int vv_debug_plan_sweep(int W, int H, const camera_params *cam, const vv_ray_sou
     const int v[12] = {S.enabled, S.major, S.sgn, S.wx, S.wy, S.pxc, S.ry, S.group, S.ring, S.ntx, S.nty, S.nl};
     memcpy(out, v, sizeof v);
     return VV_OK;
+#endif
+}
+
+// 1 in the experimental build (libvolviz_hip_x.so: march_skew_kernel, sweep_kernel and march_phong2_kernel behind VV_SKEW / VV_SWEEP / VV_PHONG2), 0 in the product
+int vv_build_is_experimental(void)
+{
+#ifdef VV_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int vv_reread_env(vv_context *c)
@@ -453,7 +466,9 @@ int vv_load_volume_stream_slices_async(vv_context *c, const void *src, int src_t
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->pin_ev[b], c->promo_stream));
         }
-        c->src_last = pinned ? b : -1;             // (pageable sources were copied into our own staging buffer above)
+        // (pageable sources were copied into our own staging buffer above.)  An outstanding pinned source stays outstanding when a
+        // pageable piece follows: copies are ordered on copy_stream, so this piece's event covers the earlier ones.
+        if (pinned || c->src_last >= 0) c->src_last = b;
         done += nv;
     }
     return VV_OK;
@@ -858,11 +873,13 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // Skewed lock step (march_skew_kernel, speed only): lanes of a wave aligned along the axis the rays march along (y or
     // z, whichever the central ray crosses more steeply in voxels per sample).  VV_SKEW=0/1/2 overrides (1 / 2: the axis).
     A.strips.skew_axis = 0;
+#ifdef VV_EXPERIMENTAL
     if (rays->mode == VV_RAYS_ANALYTIC && !shading->phongShading) {
         const float sy = fabsf(P.look[1] * P.step[1] * P.inv_scale[1] * (float)c->ny), sz = fabsf(P.look[2] * P.step[2] * P.inv_scale[2] * (float)c->nz);
         const int ax = sz >= sy ? 2 : 1;
         if (K.skew > 0) A.strips.skew_axis = K.skew <= 2 ? K.skew : ax;
     }
+#endif
     // Block shape (speed only).  32 x 2 wave tiles: stacked (32 x 8 pixels), 2 x 2 (64 x 4) or side by side (128 x 2): the partial lines two x-adjacent wave
     // tiles share are then fetched within one block; strips get lower.  8 x 8 wave tiles: side by side (32 x 8), 2 x 2 (16 x 16) or stacked (8 x 32).  VV_BLOCK_W=8...128.
     //   measured (tools/ab_env.sh, profiles/r03_block_shape.txt): 64 x 4: C3 -2.4 % (EA bytes 1.474 -> 1.364 x algorithmic), u8 1024^3 -1.3 %, tilted views -1.7 %, but
@@ -929,11 +946,6 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (rc) return rc;
     A.rad = c->d_rad; A.rad_out = c->d_rad;
     A.counter = c->d_counter;
-    A.phong_gate = nullptr; A.phong_gate_max = 0;
-    if (K.phong_gate > 0 && shading->phongShading) {
-        if (!c->d_gate) { if (hipMalloc((void **)&c->d_gate, 65536 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); c->d_gate = nullptr; } }
-        if (c->d_gate) { HIPCHK(c, hipMemsetAsync(c->d_gate, 0, 65536 * sizeof(int), st)); A.phong_gate = c->d_gate; A.phong_gate_max = K.phong_gate; }
-    }
 
     const size_t fb = (size_t)W * H * 4;
     uint8_t *d_out = rgba_out;
@@ -966,8 +978,9 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); } else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big || beyond_caches) launch_raymarch_big(A, st); else launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
-        // Slab sweep (vv_sweep.hip): the volume streamed through an LDS slice ring (opt-in).
         bool sweep = false;
+#ifdef VV_EXPERIMENTAL
+        // Slab sweep (vv_sweep.hip): the volume streamed through an LDS slice ring (opt-in: VV_SWEEP=1, profiles/EXPERIMENTS.md).
         if (K.sweep >= 0) sweep = K.sweep != 0;
         if (sweep) {
             const int own_bands = s_count > 1 ? A.strips.n_strips / A.strips.strips_per_band : 0;          // (the ratio does not depend on the strip height)
@@ -984,9 +997,12 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         if (sweep) {
             // the kernel reports a clamped footprint / a block that could not be served in counter[7] of EVERY frame, instrumented or not
             if (!A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter + 7, 0, sizeof(unsigned long long), st));
-            launch_raymarch_sweep(A, st);
-            sweep_frame = true; c->sweep_err_valid = true;
+            // (false: the kernel's LDS no longer fits a CU, or its attributes could not be set: the gather kernel takes the frame)
+            if (launch_raymarch_sweep(A, st)) { sweep_frame = true; c->sweep_err_valid = true; }
+            else sweep = false;
         }
+#endif
+        if (sweep) { }
         else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); }
         else if (A.V.zpair) launch_raymarch_zpair(A, st);
         else if (A.V.big) launch_raymarch_big(A, st);

@@ -54,8 +54,6 @@ struct MarchArgs {
     uint32_t *pixels;           // device RGBA8 frame
     unsigned long long *counter;
     uint32_t *bricks;
-    int *phong_gate;            // march_phong_kernel: per-CU tickets (65536 ints, zero between launches) or NULL
-    int phong_gate_max;         // blocks of one CU that may be in their refresh (gather) phase at once; 0 = no gate
 };
 
 void launch_rad(const MarchArgs &a, hipStream_t s);
@@ -70,7 +68,10 @@ void launch_repitch(const void *dense, void *pitched, size_t row_bytes /* multip
                     size_t row_pitch, size_t slice_pitch, hipStream_t s);
 size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_t *sz64);
 void launch_build_bricks(int vtype, const void *linear, size_t row_pitch, size_t slice_pitch, void *bricks, int nx, int ny, int nz, hipStream_t s);
-void launch_raymarch_sweep(const MarchArgs &a, hipStream_t s);    // block-wide slab sweep, LDS slice ring filled by LDS-DMA (f32, no Phong)
+// block-wide slab sweep, LDS slice ring filled by LDS-DMA (f32, no Phong).  False: the kernel's static + the planned dynamic LDS exceed a CU's 160 KB (or its
+// attributes cannot be set): nothing was launched, the caller takes the gather kernel
+bool launch_raymarch_sweep(const MarchArgs &a, hipStream_t s);
+bool sweep_lds_fits(size_t static_bytes, size_t dynamic_bytes);
 // host-side sizing of the sweep for a frame (fills a.sweep; enabled = 0 if the frame does not qualify)
 void plan_sweep(MarchArgs &a, int first_tile_row_px, int n_pixel_rows, int own_bands);
 // the axis (1 = y, 2 = z) and direction along which every ray of the frame crosses the volume's slices, or false

@@ -5,8 +5,8 @@
 // cache and hardware texture fetches; here
 //   * rad_kernel      computes the per-slab sphere radius (blockMin, kernel.cu:80-97,329)
 //                     once, so the march itself is free of the slab tiling;
-//   * march_kernel    (no Phong) gives every wavefront an 8x8 pixel tile, keeps the
-//                     whole ray state in registers, reconstructs samples with a
+//   * march_kernel    (no Phong) gives every wavefront a 32x2 (views along the memory axis) or
+//                     8x8 pixel tile, keeps the whole ray state in registers, reconstructs samples with a
 //                     branch-free hand-written trilinear gather from linear HBM, and
 //                     classifies through a transfer-function table staged in LDS;
 //   * march_phong_kernel keeps the slab+apron structure that central differences
@@ -349,6 +349,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
     }
 }
 
+#ifdef VV_EXPERIMENTAL
 // ---------------------------------------------------------------------------
 // march_skew_kernel: march_kernel with a per-lane sample offset ("skewed lock step").
 //
@@ -554,12 +555,7 @@ __global__ __launch_bounds__(256) void march_skew_kernel(FrameParams P, VolumeVi
     }
 }
 
-// index of the CU this wave runs on (XCC, shader engine, shader array, CU): HW_REG_XCC_ID / HW_REG_HW_ID.  Speed only.
-__device__ __forceinline__ int cu_index()
-{
-    const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508);       // (size 32, offset 0) of registers 4 and 20
-    return (int)(((xcc & 15u) << 12) | (((hw >> 13) & 7u) << 8) | (((hw >> 12) & 1u) << 7) | ((hw >> 8) & 15u));
-}
+#endif   // VV_EXPERIMENTAL
 
 // ---------------------------------------------------------------------------
 // march_phong_kernel: one block per reference slab (14x14 interior + apron),
@@ -582,7 +578,7 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
                                                           const float4 *__restrict__ tf, SlabMap M,
                                                           uint32_t *__restrict__ pixels,
                                                           unsigned long long *__restrict__ counter,
-                                                          uint32_t *__restrict__ bricks, int *__restrict__ gate, int gate_max)
+                                                          uint32_t *__restrict__ bricks)
 {
     __shared__ float4 lds_tf[256];
     __shared__ float red[256];
@@ -669,9 +665,6 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
     unsigned long long executed = 0;
     float dist = r.dist0;
     bool ert_done = false;
-#ifdef VV_PHONG_GATE_BUILD
-    int *gate_slot = nullptr; bool have_ticket = false;
-#endif
     const bool marching = writer && !skip && !r.cut_return;
     const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
     const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
@@ -708,25 +701,8 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
                 else d = wave_max_i(d);
             }
             if ((threadIdx.x & 63) == 0 && d) atomicMax(&any_live, d);
-            // Refresh gate (experiment build -DVV_PHONG_GATE_BUILD, then VV_PHONG_GATE=R): at most R blocks of a CU gather at a time, the others shade meanwhile --
-            // the refresh phases of co-resident blocks otherwise thrash the CU's 32 KB L1 against each other.  A ticket per CU in
-            // global memory (blocks of a CU share nothing else); the wait is bounded: after ~50 us the block goes ahead without one.
-#ifdef VV_PHONG_GATE_BUILD
-            if (gate_max > 0 && threadIdx.x == 0) {
-                gate_slot = gate + cu_index();
-                have_ticket = false;
-                for (int tries = 0; tries < 128; ++tries) {
-                    if (atomicAdd(gate_slot, 1) < gate_max) { have_ticket = true; break; }
-                    atomicSub(gate_slot, 1);
-                    __builtin_amdgcn_s_sleep(16);
-                }
-            }
-#endif
             __syncthreads();
             depth = any_live;
-#ifdef VV_PHONG_GATE_BUILD
-            if (!depth && gate_max > 0 && threadIdx.x == 0 && have_ticket) atomicSub(gate_slot, 1);
-#endif
             if (!depth) break;
         }
         // rayMarch: every thread refreshes its 32 cache entries for this chunk  :125-145
@@ -773,9 +749,6 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
             }
         }
         __syncthreads();
-#ifdef VV_PHONG_GATE_BUILD
-        if (gate_max > 0 && threadIdx.x == 0 && have_ticket) atomicSub(gate_slot, 1);       // every thread's gathers have landed
-#endif
         if (mine) {
             for (int i = 1; i < kCacheDepth - 1; ++i) {
 #pragma clang fp contract(off)
@@ -852,6 +825,7 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
     dim3 grid(nblocks);
     // a.lds_reserve bytes of (unused) dynamic LDS cap the number of resident blocks per CU:
     // fewer waves share the 32 KB L1, which this gather kernel needs more than latency hiding
+#ifdef VV_EXPERIMENTAL
     if (a.strips.skew_axis) {
         if (a.unroll == 3)
             hipLaunchKernelGGL((march_skew_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 3>), grid, dim3(256), (size_t)a.lds_reserve, s,
@@ -864,6 +838,7 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
                                a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
         return;
     }
+#endif
     if (a.unroll == 3)
         hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 3>), grid, dim3(256), (size_t)a.lds_reserve, s,
                            a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
@@ -891,7 +866,7 @@ static void launch_phong(const MarchArgs &a, hipStream_t s)
     }
 #endif
     hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), (size_t)a.lds_reserve_phong, s,
-                       a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks, a.phong_gate, a.phong_gate_max);
+                       a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
 }
 
 template <int SLICE, int VOXEL, bool TEX8>

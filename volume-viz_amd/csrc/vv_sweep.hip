@@ -334,7 +334,7 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
                 f.r0 = __builtin_amdgcn_readfirstlane(f.r0); f.r1 = __builtin_amdgcn_readfirstlane(f.r1);
                 const int c0 = f.x0 >> 5;
                 int ncell = (f.x1 >> 5) - c0 + 1, nrows = f.r1 - f.r0 + 1;
-                if (ncell > S.pxc || nrows > S.ry) { if (lane == 0) lds_store_i(&ctl->err, 2); ncell = min(ncell, S.pxc); nrows = min(nrows, S.ry); }
+                if (ncell > S.pxc || nrows > S.ry) { if (lane == 0) atomicOr(&ctl->err, 1 << 1); ncell = min(ncell, S.pxc); nrows = min(nrows, S.ry); }
                 const int pitch = ncell * 128, np = (nrows * pitch + kPage - 1) / kPage;
                 const int pos = head + np <= kPages ? head : 0;
                 bool busy = false;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
                 // enter through different faces at the cube's silhouette, strongly diverging rays).  Every wave sees the same
                 // numbers: the block leaves the ring here and marches on direct gathers.
                 bail = 1;
-                if (lane == 0) lds_store_i(&ctl->err, 4);
+                if (lane == 0) atomicOr(&ctl->err, 1 << 3);
             } else {
                 // wait for THIS wave's rows of the slices <= need_hi: everything but the copies issued after them
                 // (the copies issued in the trips AFTER the last one that had reached need_hi may stay in flight)
@@ -541,7 +541,13 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
     }
     // errors are always reported (a clamped footprint would mean wrong pixels): counter + 7 holds four 16-bit counts, codes 1..4
     // (code 4 -- a block left the ring because its window did not fit -- is a statistic, not an error: pixels are right)
-    if (lane == 0 && wave == 0) { const int e = lds_load_i(&ctl->err); if (e) atomicAdd(counter + 7, 1ull << (16 * (e - 1))); }
+    // (ctl->err is a bit mask, bit c - 1 for code c, so that the statistic cannot hide an error of the same block)
+    if (lane == 0 && wave == 0) {
+        const int e = lds_load_i(&ctl->err);
+        unsigned long long add = 0ull;
+        for (int c = 0; c < 4; ++c) if ((e >> c) & 1) add += 1ull << (16 * c);
+        if (add) atomicAdd(counter + 7, add);
+    }
     if (INSTR) {
         for (int q = 32; q > 0; q >>= 1) { executed += __shfl_down(executed, q); misses += __shfl_down(misses, q); }
         if (lane == 0 && executed) atomicAdd(counter, executed);
@@ -553,43 +559,60 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
     }
 }
 
+// A CU has 160 KB of LDS for a block's static and dynamic allocations together.  The ring takes nearly all of it, so one more
+// __shared__ variable in the kernel can push the launch over (round 3: HSA_STATUS_ERROR_INVALID_ALLOCATION aborted the process).
+// Once per instantiation: the kernel's static LDS from its attributes, the dynamic limit raised; false = this launch cannot be made.
+template <class K>
+static bool sweep_launchable(K kern, size_t dynamic_bytes)
+{
+    static int static_lds = -2;                        // (one per instantiation: K is a distinct function type only per signature, so keyed below)
+    static const void *keyed = nullptr;
+    if (keyed != (const void *)kern) {
+        hipFuncAttributes fa;
+        static_lds = hipFuncGetAttributes(&fa, (const void *)kern) == hipSuccess ? (int)fa.sharedSizeBytes : -1;
+        if (static_lds >= 0 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax - static_lds) != hipSuccess) static_lds = -1;
+        (void)hipGetLastError();
+        keyed = (const void *)kern;
+    }
+    return static_lds >= 0 && sweep_lds_fits((size_t)static_lds, dynamic_bytes);
+}
 template <int MAJOR, bool TEX8, bool GRAY, bool INSTR>
-static void launch_one(const MarchArgs &a, hipStream_t s)
+static bool launch_one(const MarchArgs &a, hipStream_t s)
 {
     const SweepArgs &S = a.sweep;
     const unsigned nblocks = S.order ? (unsigned)S.n_order : (unsigned)(((S.nty + 7) / 8) * 8 * S.ntx);
     if (S.steps == 1) {
         auto kern = sweep_kernel<MAJOR, TEX8, GRAY, INSTR, 1>;
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax); attr_set = true; }
+        if (!sweep_launchable(kern, (size_t)S.lds_bytes)) return false;
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3((unsigned)(S.nc * 64)), (size_t)S.lds_bytes, s,
                            a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, S);
     } else {
         auto kern = sweep_kernel<MAJOR, TEX8, GRAY, INSTR, 2>;
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax); attr_set = true; }
+        if (!sweep_launchable(kern, (size_t)S.lds_bytes)) return false;
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3((unsigned)(S.nc * 64)), (size_t)S.lds_bytes, s,
                            a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, S);
     }
+    return true;
 }
 template <int MAJOR>
-static void launch_major(const MarchArgs &a, hipStream_t s)
+static bool launch_major(const MarchArgs &a, hipStream_t s)
 {
     const bool gray = a.gray;
     if (a.tex8) {
-        if (gray) { if (a.instr) launch_one<MAJOR, true, true, true>(a, s); else launch_one<MAJOR, true, true, false>(a, s); }
-        else      { if (a.instr) launch_one<MAJOR, true, false, true>(a, s); else launch_one<MAJOR, true, false, false>(a, s); }
-    } else {
-        if (gray) { if (a.instr) launch_one<MAJOR, false, true, true>(a, s); else launch_one<MAJOR, false, true, false>(a, s); }
-        else      { if (a.instr) launch_one<MAJOR, false, false, true>(a, s); else launch_one<MAJOR, false, false, false>(a, s); }
+        if (gray) return a.instr ? launch_one<MAJOR, true, true, true>(a, s) : launch_one<MAJOR, true, true, false>(a, s);
+        return a.instr ? launch_one<MAJOR, true, false, true>(a, s) : launch_one<MAJOR, true, false, false>(a, s);
     }
+    if (gray) return a.instr ? launch_one<MAJOR, false, true, true>(a, s) : launch_one<MAJOR, false, true, false>(a, s);
+    return a.instr ? launch_one<MAJOR, false, false, true>(a, s) : launch_one<MAJOR, false, false, false>(a, s);
 }
 
 } // namespace sweepk
 
-void launch_raymarch_sweep(const MarchArgs &a, hipStream_t s)
+bool sweep_lds_fits(size_t static_bytes, size_t dynamic_bytes) { return static_bytes + dynamic_bytes <= (size_t)sweepk::kLdsMax; }
+
+bool launch_raymarch_sweep(const MarchArgs &a, hipStream_t s)
 {
-    if (a.sweep.major == 2) sweepk::launch_major<2>(a, s); else sweepk::launch_major<1>(a, s);
+    return a.sweep.major == 2 ? sweepk::launch_major<2>(a, s) : sweepk::launch_major<1>(a, s);
 }
 
 bool sweep_axis(const FrameParams &P, const VolumeView &V, int &major, int &sgn, const char **why)

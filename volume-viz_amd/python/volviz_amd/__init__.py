@@ -19,6 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))          # volume-viz_amd/
 REPO_ROOT = os.path.normpath(os.path.join(PKG_ROOT, ".."))
 LIB_PATH = os.environ.get("VV_LIB", os.path.join(PKG_ROOT, "lib", "libvolviz_hip.so"))
+# the same sources with -DVV_EXPERIMENTAL: adds the opt-in kernels behind VV_SKEW / VV_SWEEP / VV_PHONG2 (never faster; kept as pinned experiments)
+LIB_X_PATH = os.path.join(PKG_ROOT, "lib", "libvolviz_hip_x.so")
 
 # kernel.cuh:18-20
 SLICE_NONE, SLICE_PLANE, SLICE_PLANE_CUT = -1, 0, 1
@@ -80,10 +82,11 @@ EXPORTS = [
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
     "vv_prepare_layouts", "vv_device_bytes", "vv_debug_sweep_trace", "vv_reread_env", "vv_debug_plan_sweep",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
-    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset", "vv_debug_last_launch",
+    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset", "vv_debug_last_launch", "vv_build_is_experimental",
 ]
 
 _lib = None
+_libs = {}
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:
@@ -91,6 +94,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
+    if path is not None and path in _libs:
+        return _libs[path]
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise RuntimeError(f"{p} not found: build it with `make -C {PKG_ROOT}` "
@@ -150,6 +155,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
             fn.restype = i
     if path is None:
         _lib = lib
+    else:
+        _libs[path] = lib
     return lib
 
 
@@ -208,8 +215,9 @@ class Camera:
 
 def plan_sweep(width: int, height: int, cam: "Camera", step: float, voxel_type: int, dims, phong: bool = False,
                slice_type: int = SLICE_NONE, rays=None) -> dict:
-    """vv_debug_plan_sweep: the slab-sweep planner's decision for a frame (host arithmetic only, needs no GPU)."""
-    lib = load_library()
+    """vv_debug_plan_sweep: the slab-sweep planner's decision for a frame (host arithmetic only, needs no GPU).  The sweep
+    kernel and its planner are part of the experimental build of the library only."""
+    lib = load_library(LIB_X_PATH)
     cp = cam.params(width, height)
     rs = rays if rays is not None else analytic_rays(cam)
     st = (C.c_float * 3)(step, step, step) if np.isscalar(step) else (C.c_float * 3)(*step)
@@ -290,8 +298,8 @@ def make_options(step=None, ert_threshold=0.0, filter=FILTER_TEX8, ert_mode=ERT_
 class Context:
     """One vv_context: one device, one volume, one transfer function (kernel.cu:35-51)."""
 
-    def __init__(self, device: int = -1):
-        self.lib = load_library()
+    def __init__(self, device: int = -1, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
         h = C.c_void_p()
         rc = self.lib.vv_init(device, C.byref(h))
         if rc:
