@@ -353,6 +353,8 @@ def main():
                      "traffic": traffic, "algorithmic_bytes_per_launch": int(bytes_rank),
                      "bytes_per_sample": round(bytes_rank / max(samples, 1), 3)},
     }
+    out["roofline"]["traffic_source"] = (f"committed PMC pass (profiles/pmc_traffic.json, taken with csrc {csrc_sha()}: FETCH_SIZE x calibrated factor + WRITE_SIZE, tools/pmc_traffic.py); "
+                                         "not measured inside this run") if traffic is not None else "none"
     if traffic_note:
         out["roofline"]["traffic_note"] = traffic_note
     if upload is not None:
@@ -416,6 +418,138 @@ def main():
         except Exception as e:
             out["images_path"] = {"error": f"{type(e).__name__}: {e}"}
 
+    # ---- sub-records beside the metric (never at its cost): the other single-GPU configurations of BASELINE.json and the other kernel
+    #      families of the path, each on its own context so that the C3 volume above stays what `value` was measured on ----
+    def sub_timed(c, Wx, Hx, camera, o, phong, reps, warm=30):
+        fr = torch.zeros(Hx * Wx, dtype=torch.int32, device=dev)
+        for _ in range(warm):
+            c.render_device(Wx, Hx, camera, fr.data_ptr(), options=o, stream=stream, phong=phong)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            c.render_device(Wx, Hx, camera, fr.data_ptr(), options=o, stream=stream, phong=phong)
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, fr
+
+    def sub_instrumented(c, Wx, Hx, camera, stepx, phong, nvol, vb, fr):
+        nbx = (nvol + BRICK - 1) // BRICK
+        bm = torch.zeros((nbx ** 3 + 31) // 32, dtype=torch.int32, device=dev)
+        c.render_device(Wx, Hx, camera, fr.data_ptr(), options=vv.make_options(step=stepx, count_samples=True, touched_bricks=bm.data_ptr()), stream=stream, phong=phong)
+        torch.cuda.synchronize()
+        nsx = c.last_sample_count()
+        nbr = int(np.unpackbits(bm.cpu().numpy().view(np.uint8)).sum())
+        return nsx, nbr * BRICK ** 3 * vb + 4 * Wx * Hx + 4096
+
+    def pmc_sub(key):
+        pj = os.path.join(REPO, "profiles", "pmc_sub.json")
+        try:
+            j = json.load(open(pj))
+            return j.get("entries", {}).get(key), (None if j.get("csrc_sha") == csrc_sha() else f"committed with csrc {j.get('csrc_sha')}, this tree is {csrc_sha()}")
+        except Exception as e:
+            return None, f"no profiles/pmc_sub.json ({type(e).__name__})"
+
+    def sub_records():
+        if not (world == 1 and args.config == "c3" and args.view == "a" and not args.orbit and not args.phong and not os.environ.get("VV_BENCH_NO_EXTRA")):
+            return
+        cam0 = vv.Camera()
+        # -- C2 (BASELINE.json configs[1]): 256^3 f32, 1280x720, step 1/256, grey table (Head).  Lives in the caches: not HBM-bound;
+        #    reported as Msamples/s with the VALU-issue fraction of a committed PMC pass
+        try:
+            c2 = vv.Context(local)
+            n2, W2, H2 = 256, 1280, 720
+            a8 = torch.empty(n2 ** 3, dtype=torch.uint8, device=dev); c2.generate_noise_device(a8.data_ptr(), n2, n2, n2, 0x9E3779B9, stream)
+            a32 = torch.empty(n2 ** 3, dtype=torch.float32, device=dev); c2.promote_device(a8.data_ptr(), a32.data_ptr(), n2 ** 3, stream)
+            c2.load_volume_device(a32.data_ptr(), vv.VOXEL_F32, n2, n2, n2, vv.transfer_preset(vv.TF_HEAD), stream); torch.cuda.synchronize()
+            o2 = vv.make_options(step=1.0 / 256)
+            ms2, fr2 = sub_timed(c2, W2, H2, cam0, o2, False, 100, warm=100)
+            ns2, by2 = sub_instrumented(c2, W2, H2, cam0, 1.0 / 256, False, n2, 4, fr2)
+            pm, pnote = pmc_sub("c2")
+            out["c2"] = {"what": "BASELINE config C2: 256^3 f32 noise volume, 1280x720, step 1/256, Head (grey) table, view a: march_kernel on the z-pair copy; cache-resident, not HBM-bound",
+                         "ms_per_frame": round(ms2, 4), "value": round(ns2 / ms2 / 1e3, 1), "unit": "Msamples/s", "executed_samples_per_frame": int(ns2),
+                         "launch": c2.last_launch(), "algorithmic_bytes_per_launch": int(by2),
+                         "valu_issue_fraction": None if pm is None else pm.get("valu_issue_fraction"), "lds_issue_fraction": None if pm is None else pm.get("lds_issue_fraction"),
+                         "pmc_source": "committed PMC pass (profiles/pmc_sub.json: SQ_ACTIVE_INST_VALU / (32 x GRBM_GUI_ACTIVE), tools/pmc_sub.py)" + (f"; {pnote}" if pnote else "")}
+            # -- slice sampler (slice_kernel, kernel.cu:543-644) on the same volume: 256^2 (the reference's size, params.h:17) and 1024^2, device output
+            import ctypes as C
+            sl = {}
+            sc = (C.c_float * 3)(1.0, 1.0, 1.0)
+            for hw in (256, 1024):
+                buf = torch.zeros(hw * hw, dtype=torch.float32, device=dev)
+                def call():
+                    c2._chk(c2.lib.vv_slice(c2.h, buf.data_ptr(), hw, hw, 0.1, 0.2, 0.3, vv.CORONAL, C.byref(sc), 0, vv.FILTER_TEX8, 1, stream))
+                for _ in range(20): call()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(100): call()
+                e1.record(); torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 10.0
+                sl[f"{hw}x{hw}"] = {"us_per_slice": round(us, 2), "Msamples_per_s": round(hw * hw / us, 1), "bytes_written": 4 * hw * hw,
+                                    "bound": "launch latency" if us < 10 else "gather"}
+            out["slice"] = {"what": "vv_slice (coronal plane, TEX8 filter) of the 256^3 volume into a device buffer, enqueue-only calls back to back", **sl}
+            c2.close(); del a8, a32, fr2
+        except Exception as e:
+            out["c2"] = {"error": f"{type(e).__name__}: {e}"}
+        # -- generator (drawDefaultBrain, volumegenerator.cpp:100-119): HIP against the CPU restatement on one thread (as the reference is), 128^3 and 1024^3
+        try:
+            cg = vv.Context(local)
+            gen = {}
+            for ng in (128, 1024):
+                g8 = torch.empty(ng ** 3, dtype=torch.uint8, device=dev)
+                for _ in range(3): cg.generate_default_brain_device(g8.data_ptr(), ng, ng, ng, stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10): cg.generate_default_brain_device(g8.data_ptr(), ng, ng, ng, stream)
+                e1.record(); torch.cuda.synchronize()
+                msg = e0.elapsed_time(e1) / 10
+                gen[f"{ng}^3"] = {"hip_ms": round(msg, 4), "hip_GB_per_s_written": round(ng ** 3 / msg / 1e6, 1), "frac_of_hbm_peak": round(ng ** 3 / (msg * 1e-3) / HBM_PEAK, 4)}
+                del g8
+            if want_cpu:
+                sys.path.insert(0, os.path.join(REPO, "tests"))
+                import oracle_lib as O
+                t = time.perf_counter(); O.draw_default_brain(128, 128, 128); d128 = time.perf_counter() - t
+                t = time.perf_counter(); O.draw_default_brain(1024, 1024, 16); d16 = time.perf_counter() - t
+                gen["128^3"].update({"cpu_port_1thread_ms": round(d128 * 1e3, 1), "speedup": round(d128 * 1e3 / gen["128^3"]["hip_ms"], 1)})
+                gen["1024^3"].update({"cpu_port_1thread_ms_extrapolated": round(d16 * 64 * 1e3, 0), "speedup": round(d16 * 64 * 1e3 / gen["1024^3"]["hip_ms"], 0),
+                                      "cpu_sample": f"16 slices of 1024 x 1024 voxels ({d16:.2f} s; every drawEllipsoid visits every voxel, so the cost per voxel does not depend on the slice) x 64"})
+            out["generator"] = {"what": "vv_generate_default_brain (8 ellipsoids fused, ellipsoid_kernel) into a device buffer; bound: VALU (profiles/r04_generator.txt), write roofline = HBM peak", **gen}
+            cg.close()
+        except Exception as e:
+            out["generator"] = {"error": f"{type(e).__name__}: {e}"}
+        # -- C5 (BASELINE.json configs[4]) on one GPU: 2048^3 f32 streamed from one pinned host buffer, gradient + Phong, step 1/2048
+        try:
+            ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)          # release the 4 GiB C3 volume first
+            torch.cuda.empty_cache()
+            c5 = vv.Context(local)
+            n5, W5, H5, per = 2048, 1920, 1080, 32
+            b8 = torch.empty(n5 ** 3, dtype=torch.uint8, device=dev); c5.generate_noise_device(b8.data_ptr(), n5, n5, n5, 0x9E3779B9, stream); torch.cuda.synchronize()
+            pin = torch.empty((per, n5, n5), dtype=torch.uint8).pin_memory()
+            host8 = np.empty((n5, n5, n5), np.uint8)
+            bv = b8.view(n5, n5, n5)
+            for z0 in range(0, n5, per):
+                pin.copy_(bv[z0:z0 + per]); host8[z0:z0 + per] = pin.numpy()
+            del bv, b8; torch.cuda.empty_cache()
+
+            def slabs5():
+                for z0 in range(0, n5, per):
+                    pin.numpy()[...] = host8[z0:z0 + per]
+                    yield z0, pin.numpy()
+            t0u = time.perf_counter()
+            c5.load_volume_streamed(slabs5(), vv.VOXEL_F32, n5, n5, n5, tf); torch.cuda.synchronize()
+            up = time.perf_counter() - t0u
+            del host8, pin
+            o5 = vv.make_options(step=1.0 / 2048)
+            ms5, fr5 = sub_timed(c5, W5, H5, cam0, o5, True, 10, warm=10)
+            ns5, by5 = sub_instrumented(c5, W5, H5, cam0, 1.0 / 2048, True, n5, 4, fr5)
+            out["c5"] = {"what": "BASELINE config C5 on one GPU: 2048^3 f32 noise volume (32 GiB) streamed as u8 slabs of 32 slices through one pinned host buffer and promoted on the device, "
+                                 "1920x1080, step 1/2048, colour-ramp table, central-difference gradient + Phong, view a: march_phong_kernel (64-bit addressing build)",
+                         "ms_per_frame": round(ms5, 4), "value": round(ns5 / ms5 / 1e3, 1), "unit": "Msamples/s", "executed_samples_per_frame": int(ns5),
+                         "upload_seconds": round(up, 3), "upload_GB_per_s": round(n5 ** 3 / up / 1e9, 2),
+                         "roofline": {"bound": "hbm", "achieved": round(by5 / (ms5 * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                      "frac": round(by5 / (ms5 * 1e-3) / HBM_PEAK, 4), "traffic": None, "algorithmic_bytes_per_launch": int(by5)}}
+            c5.close(); del fr5
+        except Exception as e:
+            out["c5"] = {"error": f"{type(e).__name__}: {e}"}
+
     def cpu_baselines():
         if want_cpu:
             # The CPU restatement (oracle/vvo.c, OpenMP) on this box's host cores (the GPU box shares its host: 16 cores is
@@ -458,6 +592,10 @@ def main():
             out["cpu_baseline_c3"] = {"value": round(sN / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
                                       "sample": f"slab rows [{lo},{lo + rows}) of {nby} of the bench frame itself ({sN} samples in {dt:.1f} s)"}
 
+    try:
+        sub_records()
+    except Exception as e:
+        out["sub_records_error"] = f"{type(e).__name__}: {e}"
     try:
         cpu_baselines()
     except Exception as e:          # the baseline is a report beside the metric: it must never cost the metric line

@@ -333,7 +333,8 @@ size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_
     const size_t brick = vtype == VV_VOXEL_F32 ? BrickGeom<VV_VOXEL_F32>::brick : BrickGeom<VV_VOXEL_U8>::brick;
     const size_t bxv = vtype == VV_VOXEL_F32 ? BrickGeom<VV_VOXEL_F32>::bx : BrickGeom<VV_VOXEL_U8>::bx;
     const bool xcol = vtype == VV_VOXEL_F32 && BrickGeom<VV_VOXEL_F32>::halo == 0;      // no halo voxel: one more (clamped) brick column instead
-    const size_t nbx = xcol ? (size_t)nx / bxv + 1 : ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
+    const size_t bzv = vtype == VV_VOXEL_F32 ? BrickGeom<VV_VOXEL_F32>::bz : BrickGeom<VV_VOXEL_U8>::bz;
+    const size_t nbx = xcol ? (size_t)nx / bxv + 1 : ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / bzv + 1;
     size_t row = nbx * brick;                                     // brick sizes are multiples of 64
     // a row of bricks that is a multiple of 4 KiB gets 64 bytes more (same cache-channel effect as the
     // linear pitch, smaller: rotated C3 -1...-4 %, + Phong -4 %); VV_BRICK_PAD=<bytes, multiple of 64> / 0 overrides
@@ -346,18 +347,19 @@ size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_
     return nbz * layer;
 }
 
-// one thread per stored element: E elements per brick row (BX voxels + halo [+ padding]), 16 rows per brick
-template <typename T, int E, int BX>
+// one thread per stored element: E elements per brick row (BX voxels + halo [+ padding]), 4 BZ rows per brick (y fastest, then z)
+template <typename T, int E, int BX, int BZ>
 __global__ __launch_bounds__(256) void brick_kernel(const T *__restrict__ in, size_t row_pitch, size_t slice_pitch, T *__restrict__ out,
                                                     int nx, int ny, int nz, size_t nbx, size_t nby, size_t total,
                                                     size_t brow /* elements per row of bricks */, size_t blayer /* per layer */)
 {
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const int e = (int)(t % E), r = (int)((t / E) % 16);
-        const size_t b = t / (E * 16);
+        constexpr int R = 4 * BZ;
+        const int e = (int)(t % E), r = (int)((t / E) % R);
+        const size_t b = t / (E * R);
         const size_t bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
-        const int x = min((int)bx * BX + e, nx - 1), y = min((int)by * 4 + (r & 3), ny - 1), z = min((int)bz * 4 + (r >> 2), nz - 1);
-        out[bz * blayer + by * brow + bx * (size_t)(E * 16) + (size_t)(r * E + e)] =
+        const int x = min((int)bx * BX + e, nx - 1), y = min((int)by * 4 + (r & 3), ny - 1), z = min((int)bz * BZ + (r >> 2), nz - 1);
+        out[bz * blayer + by * brow + bx * (size_t)(E * R) + (size_t)(r * E + e)] =
             e <= BX ? ((const T *)((const char *)in + (size_t)z * slice_pitch + (size_t)y * row_pitch))[x] : T(0);
     }
 }
@@ -368,8 +370,10 @@ void launch_build_bricks(int vtype, const void *linear, size_t row_pitch, size_t
     const size_t bxv = vtype == VV_VOXEL_F32 ? FBX : 4;
     constexpr int FH = BrickGeom<VV_VOXEL_F32>::halo;
     const bool xcol = vtype == VV_VOXEL_F32 && FH == 0;
-    const size_t nbx = xcol ? (size_t)nx / bxv + 1 : ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / 4 + 1;
-    const size_t per_brick = vtype == VV_VOXEL_F32 ? 16 * (FBX + FH) : 128;
+    constexpr int FBZ = BrickGeom<VV_VOXEL_F32>::bz;
+    const size_t bzv = vtype == VV_VOXEL_F32 ? FBZ : 4;
+    const size_t nbx = xcol ? (size_t)nx / bxv + 1 : ((size_t)nx + bxv - 1) / bxv, nby = (size_t)ny / 4 + 1, nbz = (size_t)nz / bzv + 1;
+    const size_t per_brick = vtype == VV_VOXEL_F32 ? 4 * FBZ * (FBX + FH) : 128;
     const size_t total = nbx * nby * nbz * per_brick;
     uint32_t sy = 0, sz64 = 0;
     brick_copy_bytes(vtype, nx, ny, nz, &sy, &sz64);
@@ -377,9 +381,9 @@ void launch_build_bricks(int vtype, const void *linear, size_t row_pitch, size_t
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (vtype == VV_VOXEL_F32)
-        hipLaunchKernelGGL((brick_kernel<float, FBX + FH, FBX>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, row_pitch, slice_pitch, (float *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
+        hipLaunchKernelGGL((brick_kernel<float, FBX + FH, FBX, FBZ>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, row_pitch, slice_pitch, (float *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
     else
-        hipLaunchKernelGGL((brick_kernel<uint8_t, 8, 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, row_pitch, slice_pitch, (uint8_t *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
+        hipLaunchKernelGGL((brick_kernel<uint8_t, 8, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, row_pitch, slice_pitch, (uint8_t *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
 }
 
 // ---------------------------------------------------------------------------

@@ -64,8 +64,12 @@ template <int VOXEL> struct BrickGeom;
 #ifndef VV_BRICK_HALO
 #define VV_BRICK_HALO 1           // f32 rows end in a copy of the next voxel in x (0: whole-line bricks, the x pair is two gathers)
 #endif
-template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t xlog2 = VV_BRICK_XLOG2, bx = 1u << xlog2, halo = VV_BRICK_HALO, row = (bx + halo) * 4, brick = 16 * row; };
-template <> struct BrickGeom<VV_VOXEL_U8>  { static constexpr uint32_t xlog2 = 2, bx = 4, row = 8, brick = 128; };
+#ifndef VV_BRICK_ZLOG2
+#define VV_BRICK_ZLOG2 2          // f32 bricks are (1 << VV_BRICK_ZLOG2) voxels deep in z (experiment knob: 3 = 4x4x8 bricks, profiles/r04_brick_shape.txt)
+#endif
+template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t xlog2 = VV_BRICK_XLOG2, bx = 1u << xlog2, halo = VV_BRICK_HALO, row = (bx + halo) * 4,
+                                             zlog2 = VV_BRICK_ZLOG2, bz = 1u << zlog2, rows = 4 * bz, brick = rows * row; };
+template <> struct BrickGeom<VV_VOXEL_U8>  { static constexpr uint32_t xlog2 = 2, bx = 4, row = 8, zlog2 = 2, bz = 4, rows = 16, brick = 128; };
 enum { LAYOUT_LINEAR = 0, LAYOUT_LINEAR_BIG = 1, LAYOUT_BRICKED = 2, LAYOUT_ZPAIR = 3 };
 
 // Everything a frame needs that is uniform over the launch.
@@ -337,12 +341,12 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
         // bricked copy: the rows y / y+1 and the slices z / z+1 of a sample sit in the same brick
         // unless (y & 3) == 3 resp. (z & 3) == 3; the x pair always does (halo voxel)
         using G = BrickGeom<VOXEL>;
-        const uint32_t ya = iy & 3u, za = iz & 3u;
+        const uint32_t ya = iy & 3u, za = iz & (G::bz - 1u);
         const uint32_t oy0 = __umul24(iy >> 2, V.b_sy) + __umul24(ya, G::row);
         const uint32_t oy1 = oy0 + (ya == 3u ? V.b_sy - 3u * G::row : G::row);
-        const uint32_t m0  = __umul24(iz >> 2, V.b_sz64);                 // layer offset, 64-byte units
-        const uint32_t m1  = m0 + (za == 3u ? V.b_sz64 : 0u);
-        const uint32_t zi0 = __umul24(za, 4u * G::row), zi1 = za == 3u ? 0u : zi0 + 4u * G::row;
+        const uint32_t m0  = __umul24(iz >> G::zlog2, V.b_sz64);          // layer offset, 64-byte units
+        const uint32_t m1  = m0 + (za == G::bz - 1u ? V.b_sz64 : 0u);
+        const uint32_t zi0 = __umul24(za, 4u * G::row), zi1 = za == G::bz - 1u ? 0u : zi0 + 4u * G::row;
         const char *L0 = (const char *)V.bricks + ((uint64_t)m0 << 6);
         const char *L1 = (const char *)V.bricks + ((uint64_t)m1 << 6);
         if constexpr (VOXEL == VV_VOXEL_F32) {
