@@ -23,7 +23,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, sweep = -1, sweep_trace = 0, force_big = 0;
-    int skew = -1, block_w = -1, tail = -1, phong2 = -1;
+    int skew = -1, block_w = -1, tail = -1, phong2 = -1, phong_pair = -1;
     int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
@@ -31,7 +31,7 @@ struct vv_knobs {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
-        skew = geti("VV_SKEW", -1); block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1); phong2 = geti("VV_PHONG2", -1);
+        skew = geti("VV_SKEW", -1); block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1); phong2 = geti("VV_PHONG2", -1); phong_pair = geti("VV_PHONG_PAIR", -1);
         sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1);
         sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
@@ -939,6 +939,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // bricked copy likes 5: rotated C3 + Phong 2.25 -> 2.13 ms; C5 5.95 ms with 2, 6.25 with 3, 6.55 with 5)
     A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f && !use_bricks) ? 30000 : 13000);
     if (K.lds_reserve_phong >= 0 && K.lds_reserve_phong <= 146 * 1024) A.lds_reserve_phong = K.lds_reserve_phong;
+    A.phong_pair = K.phong_pair > 0 ? 1 : 0;            // (VV_PHONG_PAIR=1, experimental builds: march_phong_pair_kernel)
     A.phong_v2 = K.phong2 > 0 ? K.phong2 : 0;           // 0: march_phong_kernel; 1 / 2 (VV_PHONG2, experimental builds): march_phong2_kernel with one / two slabs per block
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;

@@ -44,6 +44,7 @@ struct MarchArgs {
     int lds_reserve;            // march_kernel: dynamic LDS bytes reserved only to cap blocks per CU
     int unroll;                 // march_kernel: samples per loop trip (2 or 3; march_skew_kernel also 1)
     int lds_reserve_phong;      // march_phong_kernel: same occupancy cap (its own LDS is 14 KB)
+    int phong_pair;             // march_phong_pair_kernel (two x-adjacent slabs per block) instead of march_phong_kernel
     int phong_v2;               // 0: march_phong_kernel; 1 / 2: march_phong2_kernel (double-buffered sample cache) with one / two slabs per block
     SweepArgs sweep;                   // sweep_kernel (vv_sweep.hip)
     StripMap strips;                   // march_kernel: strips of 8 pixel rows (n_strips of them)
