@@ -1,9 +1,9 @@
 #!/bin/bash
 # GPU box: the profile set of a round under the DRIVER's bench protocol (python3 bench.py --steps 20 --warmup 5: >= 300 launches of the headline
 # kernel, so averages are the steady state the bench line reports) -> gpurun_out/<tag>/ ; copy the summaries into profiles/.
-#   usage: tools/r03_profiles.sh <tag>
+#   usage: tools/r04_profiles.sh <tag>
 set -u
-TAG=${1:-r03prof}
+TAG=${1:-r04prof}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -3 $OUT/bench.err; exit 1; }
@@ -20,6 +20,8 @@ python3 tools/pmc_summary.py $OUT "big::march_kernel<-1, 1, true, false, false" 
 python3 tools/pmc_summary.py $OUT "brick::march_kernel<-1, 1, true, false, false" > $OUT/pmc_march_kernel_viewb_bricked.txt
 python3 tools/pmc_summary.py $OUT "big::march_phong_kernel<-1, 1, true, false>" > $OUT/pmc_march_phong_kernel.txt
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
+python3 tools/pmc_sub.py > $OUT/pmc_sub.log 2>&1 || echo "pmc_sub failed"
+cp gpurun_out/pmc_sub.json $OUT/ 2>/dev/null
 python3 tools/pmc_traffic.py > $OUT/pmc_traffic.log 2>&1 || echo "pmc_traffic failed"
 cp gpurun_out/pmc_traffic.json $OUT/ 2>/dev/null
 head -3 $OUT/pmc_march_kernel.txt; head -4 $OUT/kernel_stats.csv | cut -c1-200; tail -c 700 $OUT/bench.json

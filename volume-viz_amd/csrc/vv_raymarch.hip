@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
     __shared__ float red[256];
     __shared__ uint8_t cache[kCacheDepth][256];
     __shared__ float q255[256];              // q / 255.f for every byte q, by the same IEEE division
-    __shared__ int any_live;
+    __shared__ int any_live[2];              // refresh depth of the chunk of iteration `it`: any_live[it & 1]
     const int tid = threadIdx.x;
     // XCD-aware order (speed only, as in march_kernel): linear block L runs on XCD L % 8; XCD k takes the
     // grid rows k, k+8, ... so that the slabs of one row, which share volume lines, share an L2
@@ -600,6 +600,7 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
     // kernel.cu:175-177 divides six cached bytes by 255.f per shaded sample; a correctly rounded
     // division is ~10 instructions, a table look-up of the same quotient is one LDS read
     q255[tid] = (float)tid / 255.f;                      // visible after the barriers of the reduction below
+    if (tid < 2) any_live[tid] = 0;
 
     // grid row gy -> slab row of this shard; the last grid row is the "extra" slab row
     // nby-1 that re-writes pixel row H-2 when H == 1 (mod 14) (pin 10): it travels with
@@ -669,42 +670,41 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
     const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
     const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
 
-    for (int chunk = 0; chunk < P.max_chunks; ++chunk) {
-        bool mine = marching && !ert_done && dist < r.upper;
-        // How deep this chunk's cache has to be: a compositing ray reads its entries 0 .. n+1 and its neighbours' 1 .. n,
-        // n = the samples of the chunk before `vd > upper` (:254).  A ray whose opacity already passed the threshold (it
-        // keeps compositing one sample per chunk, pin 4) reads entries 0 .. 2 only: with every table opacity in [0, 1]
-        // the accumulated opacity cannot fall back under the threshold (res_a <= 1 stays true in float arithmetic:
-        // fl(r + fl(c * fl(1 - r))) <= 1 for r, c in [0, 1]).  The block refreshes the deepest need of its rays -- the
-        // reference refreshes all 32 always (:125-145); entries nobody reads are not observable.
-        int depth = kCacheDepth;
-        {
-            int d = 0;
-            if (mine) {
+    // How deep a chunk's cache has to be: a compositing ray reads its entries 0 .. n+1 and its neighbours' 1 .. n,
+    // n = the samples of the chunk before `vd > upper` (:254).  A ray whose opacity already passed the threshold (it
+    // keeps compositing one sample per chunk, pin 4) reads entries 0 .. 2 only: with every table opacity in [0, 1]
+    // the accumulated opacity cannot fall back under the threshold (res_a <= 1 stays true in float arithmetic:
+    // fl(r + fl(c * fl(1 - r))) <= 1 for r, c in [0, 1]).  The block refreshes the deepest need of its rays -- the
+    // reference refreshes all 32 always (:125-145); entries nobody reads are not observable.  The need of the next chunk is
+    // posted (a block-wide maximum in LDS) right after a chunk is shaded and read behind the barrier that ends the shading:
+    // two barriers per chunk.
+    auto post_need = [&](const int slot) {
+        int d = 0;
+        if (marching && !ert_done && dist < r.upper) {
 #pragma clang fp contract(off)
-                if (P.alpha_unit && res_a > P.ert_thr) d = 3;
-                else if (!(30.f * r.sstep + dist > r.upper)) d = kCacheDepth;
-                else {
-                    int n = 0;
+            if (P.alpha_unit && res_a > P.ert_thr) d = 3;
+            else if (!(30.f * r.sstep + dist > r.upper)) d = kCacheDepth;
+            else {
+                int n = 0;
 #pragma unroll 1
-                    for (int i = 1; i < kCacheDepth - 1; ++i) { const float vd = (float)i * r.sstep + dist; if (vd > r.upper) break; n = i; }
-                    d = n + 2;
-                }
+                for (int i = 1; i < kCacheDepth - 1; ++i) { const float vd = (float)i * r.sstep + dist; if (vd > r.upper) break; n = i; }
+                d = n + 2;
             }
-            if (threadIdx.x == 0) any_live = 0;
-            __syncthreads();
-            // wave maximum: nearly always decided by two ballots (some ray at full depth, or every ray past the threshold)
-            {
-                const bool full = __builtin_amdgcn_ballot_w64(d == kCacheDepth) != 0ull, deep = __builtin_amdgcn_ballot_w64(d > 3) != 0ull;
-                if (full) d = kCacheDepth;
-                else if (!deep) d = __builtin_amdgcn_ballot_w64(d != 0) != 0ull ? 3 : 0;
-                else d = wave_max_i(d);
-            }
-            if ((threadIdx.x & 63) == 0 && d) atomicMax(&any_live, d);
-            __syncthreads();
-            depth = any_live;
-            if (!depth) break;
         }
+        // wave maximum: nearly always decided by two ballots (some ray at full depth, or every ray past the threshold)
+        const bool full = __builtin_amdgcn_ballot_w64(d == kCacheDepth) != 0ull, deep = __builtin_amdgcn_ballot_w64(d > 3) != 0ull;
+        if (full) d = kCacheDepth;
+        else if (!deep) d = __builtin_amdgcn_ballot_w64(d != 0) != 0ull ? 3 : 0;
+        else d = wave_max_i(d);
+        if ((threadIdx.x & 63) == 0 && d) atomicMax(&any_live[slot], d);
+    };
+    post_need(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < P.max_chunks; ++chunk) {
+        const bool mine = marching && !ert_done && dist < r.upper;
+        const int depth = any_live[chunk & 1];                // complete: posted before the barrier above / at the end of the last chunk
+        if (!depth) break;
+        if (threadIdx.x == 0) any_live[(chunk + 1) & 1] = 0;      // posted to behind the next barrier, read behind the one after
         // rayMarch: every thread refreshes its 32 cache entries for this chunk  :125-145
         {
             float px, py, pz;
@@ -793,6 +793,7 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
 #pragma clang fp contract(off)
             dist += r.sstep * kChunkSteps;
         }
+        if (chunk + 1 < P.max_chunks) post_need((chunk + 1) & 1);
         __syncthreads();      // cache is rewritten next iteration
     }
 
