@@ -841,7 +841,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     }
     const vv_knobs &K = c->knobs;
     if (K.tile_log2w >= 3 && K.tile_log2w <= 5) A.strips.tile_log2w = K.tile_log2w;
-    // Occupancy cap + gathers in flight (speed only; measured on MI355X):
+    // Occupancy cap + gathers in flight (speed only; measured on MI355X, profiles/EXPERIMENTS.md part B section 4):
     //   volume beyond the caches (> 1 GiB), aligned view : 2 blocks per CU, 3 samples per trip
     //   volume beyond the caches, rotated, linear layout : 1 block  per CU, 3 samples per trip
     //   smaller volumes                                  : 4 blocks per CU, 3 (aligned) / 2 samples per trip

@@ -52,7 +52,7 @@ struct VolumeView {
     // ny+1 rows, nz slabs; indices beyond the volume clamp.  The two x-neighbouring records of a row
     // are the four corners (x..x+1, y, z..z+1) of a sample: one 16-byte gather per row instead of
     // two 8-byte gathers, i.e. 2 gathers per sample instead of 4 (a wave-wide gather costs the same
-    // 16 cycles for 8 and for 16 bytes per lane).  2x the volume in HBM.
+    // 16 cycles for 8 and for 16 bytes per lane, profiles/EXPERIMENTS.md part B section 4).  2x the volume in HBM.
     const void *zpair;
     uint32_t zp_row_bytes;  // (nx+1) records, u8 rows rounded up to 4 bytes
     uint32_t zp_slab_bytes; // (ny+1) * zp_row_bytes
@@ -283,7 +283,7 @@ __device__ __forceinline__ float axis_coord(float x, float n, float nm1, uint32_
 // weights.  Fetching (address arithmetic + loads) and finishing (conversion + lerps) are
 // separate so that a kernel can issue the loads of several samples back to back and only
 // then consume them -- the compiler does not reliably do that on its own, and on MI355X it
-// is worth 25 %.
+// is worth 25 % (profiles/EXPERIMENTS.md part B section 4).
 template <int VOXEL> struct Corners;
 template <> struct Corners<VV_VOXEL_F32> { float2u a, b, c, d; float wx, wy, wz; };
 template <> struct Corners<VV_VOXEL_U8>  { uint32_t a0, a1, b0, b1, c0, c1, d0, d1, sh; float wx, wy, wz; };

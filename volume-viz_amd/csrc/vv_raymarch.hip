@@ -115,7 +115,7 @@ __device__ __forceinline__ void stage_tf_planar(float *lds_tf, const float4 *__r
 // that the lanes of a gather walk one memory row; 8x8 otherwise).  blockIdx.x enumerates
 // (strip, tile) pairs of the shard (StripMap).
 //
-// Tuning (MI355X, measured): the kernel lives off the 32 KB L1 of its CU
+// Tuning (MI355X, measured, profiles/EXPERIMENTS.md part B section 4): the kernel lives off the 32 KB L1 of its CU
 // (lanes of one gather share sectors, consecutive rows of a wave share lines), so FEWER resident
 // waves are faster: the launcher reserves unused dynamic LDS to cap a CU at 1-3 blocks
 // (MarchArgs::lds_reserve) and each lane keeps U samples = 4U gathers in flight instead.

@@ -20,7 +20,7 @@
 //     s_waitcnt vmcnt) and meets the others at the one barrier of the trip;
 //   * corners come from LDS (a slice -> image table, four ds_read2_b32 x-pairs), the lerps in the oracle's order.
 // No flags, no polling, no loader / consumer roles (round 2's kernel had all three and lost to them: its flag
-// protocol alone cost 1.2 ms per C3 frame).  Every voxel line of a tile's footprint is read
+// protocol alone cost 1.2 ms per C3 frame, profiles/EXPERIMENTS.md part B section 4b).  Every voxel line of a tile's footprint is read
 // once per tile; neighbouring tiles overlap by the footprint's rim.
 //
 // Reference-mode early ray termination (kernel.cu:272-274: one sample per later 30-sample chunk) would keep the
