@@ -76,6 +76,31 @@ def test_generator_edge_cases(ctx):
         ctx.generate_ellipsoids(8, 8, 8, np.zeros((65, 3)), np.ones((65, 3)), np.ones(65, np.uint8))
 
 
+def test_generator_rows_of_whole_waves(ctx):
+    """Rows of a multiple of 1024 voxels take ellipsoid_kernel's interval form (a wave = one row; whole chunks filled from their end voxels,
+    the two chunks at the interval's ends tested voxel by voxel by 32 helper lanes): the default brain and seeded random sets -- tiny
+    ellipsoids inside one chunk, ellipsoids hanging over the volume's edges, zero and negative axes, more than 8 and more than 16 of
+    them, overlapping in paint order -- against the oracle (= the compiled reference, tests/test_oracle.py), every byte."""
+    for dims in ((1024, 40, 24), (2048, 6, 5), (1024, 1, 1)):
+        assert np.array_equal(ctx.generate_default_brain(*dims), O.draw_default_brain(*dims)), dims
+    rng = np.random.default_rng(20240)
+    for case in range(24):
+        nx = int(rng.choice([1024, 1024, 2048, 3072]))
+        ny, nz = int(rng.integers(1, 24)), int(rng.integers(1, 12))
+        n = int(rng.choice([1, 2, 5, 8, 9, 17, 40]))
+        centers = rng.uniform(-0.2, 1.2, (n, 3)).astype(np.float32)
+        axes = rng.uniform(0.002, 0.7, (n, 3)).astype(np.float32)
+        kind = case % 6
+        if kind == 1: axes[:, 0] = rng.uniform(0.0005, 0.01, n).astype(np.float32)            # intervals inside one chunk
+        if kind == 2: axes[rng.integers(0, n), rng.integers(0, 3)] = 0.0                       # division by zero: inf / NaN terms
+        if kind == 3: axes[:, 0] *= np.float32(-1.0)                                           # negative axis: the x term still falls, then rises
+        if kind == 4: centers[:, 0] = rng.choice([0.0, 1.0, 0.5, 16.0 / nx, 15.0 / nx], n).astype(np.float32)   # ends on chunk boundaries
+        colors = rng.integers(1, 256, n).astype(np.uint8)
+        got = ctx.generate_ellipsoids(nx, ny, nz, centers, axes, colors)
+        want = O.draw_ellipsoids(nx, ny, nz, centers, axes, colors)
+        assert np.array_equal(got, want), f"case {case}: {nx}x{ny}x{nz}, {n} ellipsoids, kind {kind}: {int((got != want).sum())} voxels differ"
+
+
 def test_generator_large_matches_oracle_on_slabs(ctx):
     # 512^3 on the GPU; the oracle checks it through a size-independent property: every
     # z-slice of the N^3 brain depends only on fk = k/N, so slices at k = N/4, N/2 of the

@@ -143,16 +143,19 @@ struct EllipsoidSet {
 // slab fi >= 0.99 (:85-87) is i >= i_mark, fi being monotonic in i (found on the host with the same
 // float division).  Same bytes as n calls of drawEllipsoid, 30x faster than 16 divisions per voxel.
 // Tables (floats), n8 = n rounded up to 8 with +inf in the padding (always skipped):
-//   TX[n][nx16]  TY[ny][n8]  TZ[nz][n8]  TXMIN[nx16/16][n8]      (nx16 = nx rounded up to 16)
+//   TX[n][nx16]  TY[ny][n8]  TZ[nz][n8]  TXMIN[nx16/16][n8]  TXS[n][nx16/16]  TXE[n][nx16/16]  TXM[n][nx16/16]      (nx16 = nx rounded up to 16)
 struct GenTables {
-    int nx16, nch, n8; size_t ty, tz, txmin, total;
+    int nx16, nch, n8; size_t ty, tz, txmin, txs, txe, txm, total;
     __host__ __device__ GenTables(int nx, int ny, int nz, int n)
     {
         nx16 = (nx + 15) & ~15; nch = nx16 / 16; n8 = (n + 7) & ~7;
         ty = (size_t)n * nx16;
         tz = ty + (size_t)ny * n8;
         txmin = tz + (size_t)nz * n8;
-        total = txmin + (size_t)nch * n8;
+        txs = txmin + (size_t)nch * n8;            // TXS[n][nch]: the x term of a chunk's first voxel
+        txe = txs + (size_t)n * nch;               // TXE[n][nch]: ... of its last voxel (i clamped to nx - 1)
+        txm = txe + (size_t)n * nch;               // TXM[n][nch]: the chunk minima again, ellipsoid-major (lanes of a row wave read consecutive floats)
+        total = txm + (size_t)n * nch;
     }
 };
 
@@ -177,6 +180,26 @@ __global__ __launch_bounds__(256) void ellipsoid_tables_kernel(float *__restrict
             const float fk = ((float)k) / ((float)nz);          // :46
             const float ez = e < E.n ? (E.cz[e] - fk) / E.az[e] : 0.f;
             tab[t] = e < E.n ? ez * ez : __builtin_inff();
+        } else if (t >= G.txm) {                                // smallest x term of a chunk, ellipsoid-major
+            const int e = (int)((t - G.txm) / G.nch), ch = (int)((t - G.txm) % G.nch);
+            float m = __builtin_nanf("");
+            for (int v = 0; v < 16; ++v) {
+                const int i = ch * 16 + v;
+                if (i >= nx) break;
+                const float fi = ((float)i) / ((float)nx);
+                const float ex = (E.cx[e] - fi) / E.ax[e];
+                m = fminf(m, ex * ex);
+            }
+            tab[t] = m;
+        } else if (t >= G.txs) {                                // x term of a chunk's first / last voxel
+            const bool last = t >= G.txe;
+            const size_t u = t - (last ? G.txe : G.txs);
+            const int e = (int)(u / G.nch), ch = (int)(u % G.nch);
+            int i = ch * 16 + (last ? 15 : 0);
+            if (i > nx - 1) i = nx - 1;
+            const float fi = ((float)i) / ((float)nx);
+            const float ex = (E.cx[e] - fi) / E.ax[e];
+            tab[t] = ex * ex;
         } else {                                                // smallest x term of a 16-voxel chunk
             const int ch = (int)((t - G.txmin) / G.n8), e = (int)((t - G.txmin) % G.n8);
             float m = e < E.n ? __builtin_nanf("") : __builtin_inff();
@@ -195,13 +218,40 @@ __global__ __launch_bounds__(256) void ellipsoid_tables_kernel(float *__restrict
 struct EllipsoidColors { int n; uint8_t color[kMaxEllipsoids]; };
 
 // One thread produces 16 consecutive x voxels of one (j,k) row; the store is one 16-byte write.
+//
+// ROWWAVE (rows of a multiple of 1024 voxels, fresh volumes): the 64 chunks of a wave lie in one row, and the voxels of a row that are
+// inside an ellipsoid are an INTERVAL of x -- the x term is unimodal in i (ex = (c.x - i/mx) / a.x is monotonic, its square falls then
+// rises) and every rounding on the way to fl(fl(exx + eyy) + ezz) < 1 is monotonic.  So a chunk is inside as a whole iff its first and
+// last voxel are, touched at all iff its smallest x term is, and at most two chunks of the row are touched in part: only those two get
+// the per-voxel test, by 32 lanes of the wave at once (a ballot carries the 2 x 16 results to their owners, which turn 4 bits at a time
+// into byte masks through a 16-entry table).  ~50 instructions per (row, ellipsoid) pair instead of ~96 for 16 tests in every lane, and
+// two coalesced table reads instead of sixteen values per lane.  Same bytes (test_generator_*: against the compiled reference).
+__device__ __forceinline__ void vv_gen_store16(uint8_t *p, uint4 v)
+{
+#ifdef VV_GEN_NT
+    typedef uint32_t __attribute__((ext_vector_type(4))) u4v;
+    __builtin_nontemporal_store(u4v{v.x, v.y, v.z, v.w}, (u4v *)p);
+#else
+    *(uint4 *)p = v;
+#endif
+}
+template <bool ROWWAVE>
 __global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ out, int nx, int ny, int nz, int xchunks,
                                                         int i_mark, const float *__restrict__ tab, EllipsoidColors E, int in_place)
 {
 #pragma clang fp contract(off)
     const GenTables G(nx, ny, nz, E.n);
-    const float *TX = tab, *TY = tab + G.ty, *TZ = tab + G.tz, *TXMIN = tab + G.txmin;
-    const int n8 = G.n8, nx16 = G.nx16;
+    const float *TX = tab, *TY = tab + G.ty, *TZ = tab + G.tz, *TXMIN = tab + G.txmin, *TXS = tab + G.txs, *TXE = tab + G.txe, *TXM = tab + G.txm;
+    const int n8 = G.n8, nx16 = G.nx16, nch = G.nch;
+    __shared__ uint32_t s_lut[16];                 // 4 bits -> 4 byte masks
+    if (ROWWAVE) {
+        if (threadIdx.x < 16) {
+            const uint32_t b = threadIdx.x;
+            s_lut[b] = ((b & 1u) ? 0xffu : 0u) | ((b & 2u) ? 0xff00u : 0u) | ((b & 4u) ? 0xff0000u : 0u) | ((b & 8u) ? 0xff000000u : 0u);
+        }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
     const size_t total = (size_t)xchunks * ny * nz;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int xc = (int)(t % xchunks);
@@ -210,6 +260,7 @@ __global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ ou
         const int i0 = xc * 16;
         const size_t base = row * (size_t)nx + i0;
         uint8_t vals[16];
+        uint32_t packed4[4] = {0u, 0u, 0u, 0u};                                     // (ROWWAVE keeps the 16 voxels packed)
 #pragma unroll
         for (int v = 0; v < 16; ++v) vals[v] = 0;                                   // ctor zero-fill :12-23
         if (in_place) {                                                             // else keep, :60-62
@@ -218,9 +269,13 @@ __global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ ou
         }
         // ellipsoids in batches of 8: the row / chunk terms of a batch are six 16-byte loads
         for (int e0 = 0; e0 < E.n; e0 += 8) {
-            const float4 *py = (const float4 *)(TY + (size_t)j * n8 + e0), *pz = (const float4 *)(TZ + (size_t)k * n8 + e0);
-            const float4 *pm = (const float4 *)(TXMIN + (size_t)xc * n8 + e0);
-            const float4 y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1], m0 = pm[0], m1 = pm[1];
+            // (row wave: j and k are the same in every lane; saying so lets the row terms come through scalar loads and the row test be a scalar branch,
+            //  and the chunk minimum is read only for the ellipsoids that touch the row)
+            const int ju = ROWWAVE ? __builtin_amdgcn_readfirstlane(j) : j, ku = ROWWAVE ? __builtin_amdgcn_readfirstlane(k) : k;
+            const float4 *py = (const float4 *)(TY + (size_t)ju * n8 + e0), *pz = (const float4 *)(TZ + (size_t)ku * n8 + e0);
+            const float4 y0 = py[0], y1 = py[1], z0 = pz[0], z1 = pz[1];
+            float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+            if (!ROWWAVE) { const float4 *pm = (const float4 *)(TXMIN + (size_t)xc * n8 + e0); m0 = pm[0]; m1 = pm[1]; }
             const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
             const float zz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
             const float mn[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
@@ -230,6 +285,34 @@ __global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ ou
                 if (e >= E.n) break;
                 const float eyy = yy[q], ezz = zz[q];
                 if (eyy + ezz >= 1.0f) continue;                    // no voxel of this row is inside (see above)
+                if (ROWWAVE) {
+                    // (the branch above was taken by the whole wave or by none: the wave is one row)
+                    const float xs = TXS[(size_t)e * nch + xc], xe = TXE[(size_t)e * nch + xc];
+                    const float xm = TXM[(size_t)e * nch + xc];
+                    const bool fs = (xs + eyy) + ezz < 1.0f, fe = (xe + eyy) + ezz < 1.0f, fm = (xm + eyy) + ezz < 1.0f;
+                    const bool full = fs && fe, part = fm && !full;
+                    const uint32_t col4 = (uint32_t)E.color[e] * 0x01010101u;
+                    const unsigned long long bp = __builtin_amdgcn_ballot_w64(part);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) packed4[d] = full ? col4 : packed4[d];
+                    if (bp != 0ull) {
+                        const int ca = __builtin_ctzll(bp);
+                        const unsigned long long bp2 = bp & (bp - 1ull);
+                        const int cb = bp2 ? __builtin_ctzll(bp2) : -1;
+                        const int cg = lane < 16 ? ca : cb;
+                        const bool helper = lane < 32 && cg >= 0;
+                        const float xv = helper ? TX[(size_t)e * nx16 + 16 * (size_t)(xc - lane + cg) + (lane & 15)] : __builtin_inff();
+                        const bool pv = helper && (xv + eyy) + ezz < 1.0f;                  // :57-59
+                        const uint32_t m32 = (uint32_t)__builtin_amdgcn_ballot_w64(pv);
+                        const uint32_t my16 = lane == ca ? (m32 & 0xffffu) : (lane == cb ? (m32 >> 16) : 0u);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const uint32_t bm = s_lut[(my16 >> (4 * d)) & 15u];
+                            packed4[d] = (packed4[d] & ~bm) | (col4 & bm);
+                        }
+                    }
+                    continue;
+                }
                 if ((mn[q] + eyy) + ezz >= 1.0f) continue;          // ... nor of this chunk
                 const float4 *tx = (const float4 *)(TX + (size_t)e * nx16 + i0);
                 const uint8_t col = E.color[e];
@@ -244,6 +327,15 @@ __global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ ou
                     }
                 }
             }
+        }
+        if (ROWWAVE) {                                          // (rows are multiples of 1024 voxels: whole, aligned chunks)
+            if (E.n > 0 && i0 + 15 >= i_mark) {                 // :85-87, after the last drawEllipsoid
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    if (i0 + v >= i_mark) packed4[v >> 2] = (packed4[v >> 2] & ~(0xffu << (8 * (v & 3)))) | (4u << (8 * (v & 3)));
+            }
+            vv_gen_store16(out + base, make_uint4(packed4[0], packed4[1], packed4[2], packed4[3]));
+            continue;
         }
         if (E.n > 0 && i0 + 15 >= i_mark) {                     // :85-87, after the last drawEllipsoid
 #pragma unroll
@@ -291,9 +383,17 @@ void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
     const int xchunks = (nx + 15) / 16;
     const size_t total = (size_t)xchunks * ny * nz;
     size_t blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    // blocks of 256 chunks, grid-stride beyond 65536 of them: busy and empty rows mix better over many short blocks (drawDefaultBrain at 1024^3: 1.03 ms with
+    // 1024 blocks, 0.50 with 8192, 0.46 with 65536, 0.51 with one block per 256 chunks; the fill alone 0.26 / 0.27 / 0.20 / 0.22 ms)
+    size_t cap = 65536;
+    if (const char *e = getenv("VV_GEN_BLOCKS")) { const long v = atol(e); if (v >= 256) cap = (size_t)v; }     // (experiment knob)
+    if (blocks > cap) blocks = cap;
     if (blocks == 0) return;
-    hipLaunchKernelGGL(ellipsoid_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, nx, ny, nz, xchunks, i_mark, scratch, Cc, in_place);
+    // rows of whole waves (a multiple of 1024 voxels) of a fresh volume take the interval form
+    if (!in_place && n > 0 && xchunks % 64 == 0 && nx % 16 == 0)
+        hipLaunchKernelGGL(ellipsoid_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, out, nx, ny, nz, xchunks, i_mark, scratch, Cc, in_place);
+    else
+        hipLaunchKernelGGL(ellipsoid_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, out, nx, ny, nz, xchunks, i_mark, scratch, Cc, in_place);
 }
 
 // ---------------------------------------------------------------------------
