@@ -226,3 +226,32 @@ def test_sweep_planner_decisions():
     rs = vv.analytic_rays(vv.Camera(), quantize8=True)
     assert vv.plan_sweep(1920, 1080, vv.Camera(), 1 / 512, vv.VOXEL_F32, (n, n, n), rays=rs)["enabled"] == 0
     assert vv.plan_sweep(1920, 1080, vv.Camera(), 1 / 512, vv.VOXEL_F32, (1023, n, n))["enabled"] == 0     # rows not 16-byte aligned
+
+
+def test_developer_tools_parse():
+    """tools/ holds the developer aids the profiles under profiles/ were taken with (they run on the GPU box).  None of them is part of the product;
+    this keeps them from rotting silently: every Python tool compiles, every shell tool passes `bash -n`, and no tool names a `VV_*` knob the library
+    does not read (a variant that sets an unknown knob would silently measure the default)."""
+    import py_compile, subprocess, re
+    tools = os.path.join(REPO, "tools")
+    api = open(os.path.join(REPO, "volume-viz_amd", "csrc", "vv_api.cpp")).read() + open(os.path.join(REPO, "volume-viz_amd", "csrc", "vv_aux.hip")).read()
+    known = set(re.findall(r'"(VV_[A-Z0-9_]+)"', api))
+    known |= {"VV_LIB", "VV_BENCH_NO_EXTRA", "VV_BENCH_SPINUP", "VV_BENCH_SHARE_GPU", "VV_BENCH_SYNC_GATHER", "VV_BENCH_FRAME_SHA", "VV_STATS", "VV_CPU_THREADS",
+              "VV_PITCH_PAD", "VV_PITCH_FORCE"}
+    src = open(os.path.join(REPO, "volume-viz_amd", "csrc", "vv_api.cpp")).read()
+    known |= set(re.findall(r'getenv\("(VV_[A-Z0-9_]+)"\)', src))
+    for root, _, files in os.walk(tools):
+        if "__pycache__" in root or os.sep + "bin" in root:
+            continue
+        for f in files:
+            path = os.path.join(root, f)
+            if f.endswith(".py"):
+                py_compile.compile(path, doraise=True)
+            elif f.endswith(".sh"):
+                assert subprocess.run(["bash", "-n", path]).returncode == 0, path
+            else:
+                continue
+            for name in set(re.findall(r"\b(VV_[A-Z][A-Z0-9_]+)\b", open(path).read())):
+                if name.startswith(("VV_BENCH", "VV_GEN_")) or name in ("VV_EXPERIMENTAL", "VV_RAYS_IMAGES", "VV_RAYS_ANALYTIC"):
+                    continue
+                assert name in known, f"{os.path.relpath(path, REPO)} uses {name}, which nothing reads"
