@@ -327,6 +327,11 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
             const int target = min(min((int)floorf(hi_ahead) + 1, kmaxT), lo_free + (kTab - 2));
             int cnt0 = 0;
             if (INSTR) tc0 = __builtin_readcyclecounter();
+            // (the `busy` test below reads ctl->owner[], which only wave 0 writes, and nothing orders that inside this loop: a trip must therefore never
+            //  place a slice on pages it handed out itself -- decided from scalars every wave holds identically: once the ring has wrapped in this trip,
+            //  allocations stop short of the trip's first page)
+            const int trip_first = head;
+            bool wrapped = false;
             while (issued_k < target) {
                 const int k = issued_k + 1, sl = kmul * k + kadd;
                 Foot f = footprint(FL, sl, nx, nr);
@@ -336,7 +341,9 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
                 int ncell = (f.x1 >> 5) - c0 + 1, nrows = f.r1 - f.r0 + 1;
                 if (ncell > S.pxc || nrows > S.ry) { if (lane == 0) atomicOr(&ctl->err, 1 << 1); ncell = min(ncell, S.pxc); nrows = min(nrows, S.ry); }
                 const int pitch = ncell * 128, np = (nrows * pitch + kPage - 1) / kPage;
-                const int pos = head + np <= kPages ? head : 0;
+                const bool wraps = !(head + np <= kPages);
+                const int pos = wraps ? 0 : head;
+                if ((wrapped || wraps) && pos + np > trip_first) break;        // would land on pages of this very trip: next trip
                 bool busy = false;
                 for (int b0 = 0; b0 < np; b0 += 64)
                     if (b0 + lane < np) { const int ow = lds_load_i(&ctl->owner[pos + b0 + lane]); busy = busy || !(ow < lo_free || ow == k); }
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
                     }
                 }
                 if (INSTR && wave == 0) staged += (unsigned long long)nrows * pitch;
-                head = __builtin_amdgcn_readfirstlane(pos + np); issued_k = k;
+                head = __builtin_amdgcn_readfirstlane(pos + np); issued_k = k; wrapped = wrapped || wraps;
             }
             if (INSTR) { const unsigned long long tn = __builtin_readcyclecounter(); tc_issue += tn - tc0; tc0 = tn; }
             int bail = 0;
