@@ -489,6 +489,22 @@ def main():
             c2.close(); del a8, a32, fr2
         except Exception as e:
             out["c2"] = {"error": f"{type(e).__name__}: {e}"}
+        # -- the reference's own voxel type (kernel.cu:46,459: u8; f32 volumes are this build's extension): C3's frame on the 1024^3 volume as u8
+        try:
+            cu = vv.Context(local)
+            nu = 1024
+            u8v = torch.empty(nu ** 3, dtype=torch.uint8, device=dev); cu.generate_noise_device(u8v.data_ptr(), nu, nu, nu, 0x9E3779B9, stream)
+            cu.load_volume_device(u8v.data_ptr(), vv.VOXEL_U8, nu, nu, nu, tf, stream); torch.cuda.synchronize()
+            ou = vv.make_options(step=1.0 / 512)
+            msu, fru = sub_timed(cu, W, H, cam0, ou, False, 20, warm=60)
+            nsu, byu = sub_instrumented(cu, W, H, cam0, 1.0 / 512, False, nu, 1, fru)
+            out["u8_volume"] = {"what": "C3's frame and step on the same noise volume stored as u8, the reference's voxel type (1 GiB): march_kernel on the z-pair copy",
+                                "ms_per_frame": round(msu, 4), "value": round(nsu / msu / 1e3, 1), "unit": "Msamples/s", "executed_samples_per_frame": int(nsu), "launch": cu.last_launch(),
+                                "roofline": {"bound": "hbm", "achieved": round(byu / (msu * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                             "frac": round(byu / (msu * 1e-3) / HBM_PEAK, 4), "traffic": None, "algorithmic_bytes_per_launch": int(byu)}}
+            cu.close(); del u8v, fru
+        except Exception as e:
+            out["u8_volume"] = {"error": f"{type(e).__name__}: {e}"}
         # -- generator (drawDefaultBrain, volumegenerator.cpp:100-119): HIP against the CPU restatement on one thread (as the reference is), 128^3 and 1024^3
         try:
             cg = vv.Context(local)
