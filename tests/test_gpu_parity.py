@@ -669,6 +669,45 @@ def test_phong_forced_on_the_random_cases(ctx):
             assert n_got == n
 
 
+PHONG_FORMS = [{"VV_PHONG2": "1"}, {"VV_PHONG2": "2"}, {"VV_PHONG_PAIR": "1"}, {"VV_PHONG2": "1", "VV_BRICKED": "1"}, {"VV_PHONG_PAIR": "1", "VV_FORCE_BIG": "1"},
+               {"VV_PHONG2": "2", "VV_BRICKED": "1"}]
+
+
+@pytest.mark.parametrize("form", range(len(PHONG_FORMS)))
+def test_experimental_phong_forms_are_bit_identical(xctx, form, monkeypatch):
+    """The Phong march's rebuilt forms of round 4 (experimental build only: march_phong2_kernel with one / two slabs per block -- batched, packed-fp32
+    shading, division cores, eight post-ERT chunks per barrier pair -- and march_phong_pair_kernel, the first kernel with two slabs per block): the
+    random cases with Phong forced on (cutting planes, both ERT modes and filters, odd frame widths, tables with any opacity), a mid-size frame on both
+    cameras and a sharded one, instrumented and not -- same frames, same sample counts as the oracle.  None of them is faster than march_phong_kernel
+    (profiles/r04_phong_forms.txt); the test keeps the record of that result honest."""
+    ctx = xctx
+    for k, v in PHONG_FORMS[form].items():
+        monkeypatch.setenv(k, v)
+    for seed in range(form, 48, 6):
+        vol, tf, W, H, cam, sp, _, o = _random_case(seed)
+        ctx.load_volume(vol, tf)
+        opts = vv.make_options(**o)
+        got = ctx.render(W, H, cam, slice=sp, phong=True, options=opts, fill=0x3C)
+        n_got = ctx.last_sample_count()
+        want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=True, options=opts, fill=0x3C)
+        what = f"{PHONG_FORMS[form]} seed {seed}: {vol.shape} {vol.dtype} {W}x{H} {o}"
+        assert_frames_close(got, want, what)
+        assert n_got == n, what
+        o2 = dict(o); o2["count_samples"] = False
+        assert np.array_equal(ctx.render(W, H, cam, slice=sp, phong=True, options=vv.make_options(**o2), fill=0x3C), got), what + " (uninstrumented)"
+    vol = O.draw_default_brain(64, 64, 64)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    ctx.load_volume(vol, tf)
+    for W, H, shard in ((170, 170, None), (43, 57, None), (300, 200, (4, 3, 1))):
+        o = vv.make_options(count_samples=True, shard=shard)
+        for cam in (_cam("a"), _cam("b")):
+            got = ctx.render(W, H, cam, phong=True, options=o, fill=7)
+            n_got = ctx.last_sample_count()
+            want, n = O.render(vol, tf, W, H, cam, phong=True, options=o, fill=7)
+            assert_frames_close(got, want, f"{PHONG_FORMS[form]} {W}x{H} shard={shard}")
+            assert n_got == n
+
+
 SKEW_ENVS = [{"VV_SKEW": "3"}, {"VV_SKEW": "1", "VV_UNROLL": "1"}, {"VV_SKEW": "2", "VV_UNROLL": "2"}, {"VV_SKEW": "3", "VV_FORCE_BIG": "1"},
              {"VV_SKEW": "3", "VV_ZPAIR": "1"}, {"VV_SKEW": "2", "VV_BRICKED": "1"}]
 
