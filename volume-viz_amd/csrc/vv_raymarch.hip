@@ -557,6 +557,34 @@ __global__ __launch_bounds__(256) void march_skew_kernel(FrameParams P, VolumeVi
 
 #endif   // VV_EXPERIMENTAL
 
+// x / d and sqrt(x), IEEE-exact, without their range handling.  The compiler's expansion of `/` and sqrtf is a fixed core (v_rcp + one
+// Newton step, quotient + two residual corrections; v_sqrt + a test of the two neighbouring floats) wrapped in v_div_scale x 2 + v_div_fixup
+// resp. a 2^32 pre-scale and a class test: 11 and 14 instructions.  With operands known to be normal and far from the ends of the range --
+// decided per frame on the host (FrameParams::safe_div: pixel tangents in [2^-24, 2^8], steps in [1e-5, 16]; numerators are 0 or differences
+// of q / 255, so quotients lie in [2^-26, 2^42] and their squares' sum in [2^-52, 2^86]) -- the wrappers do nothing (v_div_scale returns its
+// operand, v_div_fmas is a plain fma, v_div_fixup passes normal quotients through) and the cores alone give the same bits: 8 and 8 instructions,
+// 18 fewer per lit sample.  Round 4: C3 + Phong -4 %, C2 + Phong -11 %, u8 -9 %, the 3840 x 2160 frame -11 % (profiles/r04_phong_forms.txt F).
+__device__ __forceinline__ float ph_div_core(float n, float d)
+{
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, y0, 1.0f);
+    const float y = __builtin_fmaf(e, y0, y0);
+    const float q0 = n * y;
+    const float r0 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(r1, y, q1);
+}
+__device__ __forceinline__ float ph_sqrt_core(float x)
+{
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s0) - 1u), sp = __uint_as_float(__float_as_uint(s0) + 1u);
+    const float t1 = __builtin_fmaf(-sm, s0, x);
+    float s = (0.f >= t1) ? sm : s0;
+    const float t2 = __builtin_fmaf(-sp, s0, x);
+    s = (0.f < t2) ? sp : s;
+    return s;
+}
 // ---------------------------------------------------------------------------
 // march_phong_kernel: one block per reference slab (14x14 interior + apron),
 // 32-deep byte cache in LDS exactly as kernel.cu:125-145 lays it out, but indexed
@@ -766,11 +794,21 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
                     // it is not normalised (:180) and direct = clamp(0) = 0 -- skip the divisions
                     if (!(qr == ql && qt == qb && qa == qf)) {
                         float f = q255[qf], a = q255[qa], l = q255[ql], rr = q255[qr], t = q255[qt], b = q255[qb];
-                        float gx = (rr - l) / (P.tan_fov_x * vd), gy = (t - b) / (P.tan_fov_y * vd),
-                              gz = (a - f) / (r.sstep * 2.f);                         // :175-178, :259-263
-                        if (gx != 0.f && gy != 0.f && gz != 0.f) {
-                            float inv = 1.0f / sqrtf(gx * gx + gy * gy + gz * gz);
-                            gx *= inv; gy *= inv; gz *= inv;
+                        // :175-178, :259-263.  The three divisions, the square root and the reciprocal are IEEE-exact either way; when the frame's
+                        // operands are known to stay far inside the normal range (FrameParams::safe_div) their cores alone give the same bits (ph_div_core)
+                        float gx, gy, gz;
+                        if (P.safe_div) {
+                            gx = ph_div_core(rr - l, P.tan_fov_x * vd); gy = ph_div_core(t - b, P.tan_fov_y * vd); gz = ph_div_core(a - f, r.sstep * 2.f);
+                            if (gx != 0.f && gy != 0.f && gz != 0.f) {
+                                float inv = ph_div_core(1.0f, ph_sqrt_core(gx * gx + gy * gy + gz * gz));
+                                gx *= inv; gy *= inv; gz *= inv;
+                            }
+                        } else {
+                            gx = (rr - l) / (P.tan_fov_x * vd); gy = (t - b) / (P.tan_fov_y * vd); gz = (a - f) / (r.sstep * 2.f);
+                            if (gx != 0.f && gy != 0.f && gz != 0.f) {
+                                float inv = 1.0f / sqrtf(gx * gx + gy * gy + gz * gz);
+                                gx *= inv; gy *= inv; gz *= inv;
+                            }
                         }
                         direct = (gx * -1.f + gy * -1.f + gz * 1.f) * 0.3f;           // :183
                         direct = fmaxf(0.f, fminf(direct, 0.3f));
