@@ -61,7 +61,8 @@ def case(seed):
 
 def main():
     lo, hi = int(sys.argv[1]), int(sys.argv[2])
-    ctx = vv.Context(0)
+    # FUZZ_X=1: the experimental build of the library (the VV_SWEEP / VV_SKEW entries of ENVS select kernels only it has; the product ignores them)
+    ctx = vv.Context(0, lib_path=vv.LIB_X_PATH) if os.environ.get("FUZZ_X") == "1" else vv.Context(0)
     bad = 0
     only = os.environ.get("FUZZ_ENV_ONLY")          # index into ENVS: run only the seeds that use that entry
     for seed in range(lo, hi):
