@@ -24,7 +24,7 @@ struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, sweep = -1, sweep_trace = 0, force_big = 0;
     int skew = -1, block_w = -1, tail = -1, phong2 = -1, phong_pair = -1;
-    int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_verbose = 0;
+    int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_blocks = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
     {
@@ -32,7 +32,7 @@ struct vv_knobs {
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
         skew = geti("VV_SKEW", -1); block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1); phong2 = geti("VV_PHONG2", -1); phong_pair = geti("VV_PHONG_PAIR", -1);
-        sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1);
+        sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1); sw_blocks = geti("VV_SWEEP_BLOCKS", -1);
         sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
         sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
     }
@@ -335,7 +335,7 @@ int vv_debug_plan_sweep(int W, int H, const camera_params *cam, const vv_ray_sou
     A.V.data = (const void *)(uintptr_t)256; A.V.nx = nx; A.V.ny = ny; A.V.nz = nz;
     A.V.row_bytes = (uint32_t)nx * vsz; A.V.slice_bytes = A.V.row_bytes * (uint32_t)ny;
     A.V_type = voxel_type; A.phong = phong != 0;
-    A.sweep.wx = A.sweep.wy = A.sweep.ahead = A.sweep.steps = -1;
+    A.sweep.wx = A.sweep.wy = A.sweep.ahead = A.sweep.steps = A.sweep.blocks = -1;
     A.sweep.verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
     const int last_written = H >= 2 ? H - 2 : 0;
     plan_sweep(A, 0, ((last_written + 1 + 7) / 8) * 8, 0);
@@ -985,7 +985,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         if (K.sweep >= 0) sweep = K.sweep != 0;
         if (sweep) {
             const int own_bands = s_count > 1 ? A.strips.n_strips / A.strips.strips_per_band : 0;          // (the ratio does not depend on the strip height)
-            A.sweep.wx = K.sw_wx; A.sweep.wy = K.sw_wy; A.sweep.ahead = K.sw_ahead; A.sweep.steps = K.sw_steps;
+            A.sweep.wx = K.sw_wx; A.sweep.wy = K.sw_wy; A.sweep.ahead = K.sw_ahead; A.sweep.steps = K.sw_steps; A.sweep.blocks = K.sw_blocks;
             A.sweep.verbose = K.sw_verbose;
             plan_sweep(A, A.strips.y0, rows_px_8, own_bands);
             sweep = A.sweep.enabled != 0;

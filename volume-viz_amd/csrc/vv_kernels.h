@@ -28,8 +28,10 @@ struct SweepArgs {
     int ahead;             // trips the copies run ahead of the march
     int steps;             // sample steps per trip (1 or 2)
     int wmax;              // widest slice window (in slices) a consumer wave may need and still use the ring
-    int pxc, ry, ring;     // LDS image of a slice: ry rows of pxc 128-byte cells; `ring` slots (power of two)
-    int slot_bytes;        // pxc * 128 * ry
+    int pxw, ry, ring;     // LDS image of a slice: ry rows of pxw voxels (a multiple of 4); `ring` such slots
+    int pxc;               // (row pitch in 128-byte lines: planner output for the record)
+    int slot_bytes;        // pxw * 4 * ry
+    int blocks;            // requested blocks per CU (0 / -1: the planner's choice)
     int lds_bytes;         // dynamic LDS of the launch
     unsigned long long *trace;   // developer trace (VV_SWEEP_TRACE=1): 8 words per block, or NULL
     const int *order;      // optional tile order (device), n_order entries; NULL = XCD-interleaved raster order

@@ -13,16 +13,19 @@
 //     that at block step tau ALL rays of the tile sit within about one sample spacing of a common front along the
 //     sweep axis; the slices a trip of U steps needs are then a window of ~8-10 slices known from scalars
 //     (two block-wide extremes re-anchored every kAnchorTrips trips, run forward on the extreme slopes);
-//   * ALL waves copy: each trip every wave issues its share (rows r = wave mod NW) of the slices the block will
-//     need kAhead trips later, HBM -> LDS with `global_load_lds_dwordx4` (whole 128-byte cells, one image row per
-//     wave instruction, no registers), into a page-granular ring whose layout every wave derives from the same
-//     footprints (no allocation protocol); then waits for ITS OWN rows of the slices this trip needs (a counted
-//     s_waitcnt vmcnt) and meets the others at the one barrier of the trip;
-//   * corners come from LDS (a slice -> image table, four ds_read2_b32 x-pairs), the lerps in the oracle's order.
+//   * ALL waves copy.  The image of slice k in LDS is a fixed S.ry rows x S.pxw voxels in ring slot k mod S.ring, its origin a
+//     closed form of k (fixed-point lower bounds of the tile's footprint, SALU arithmetic, the same in every wave): no
+//     allocation, no ownership table, no per-slice footprint evaluation.  An image is dealt to the waves in 16-byte units
+//     (unit u -> LDS byte 16 u; wave w copies units [64 w, 64 w + 64) (+ 64 NW ...)): one `global_load_lds_dwordx4` with a
+//     scalar base and a per-lane offset that is computed once per kernel.  Each trip every wave issues its units of the
+//     slices the block will need up to kAhead trips later, waits for ITS OWN units of the slices this trip reads (a counted
+//     s_waitcnt vmcnt: copies retire in order) and meets the others at the one barrier of the trip;
+//   * corners come from LDS: one 8-byte read of the table (slice -> byte address of voxel (0, 0) of its image; the pitch is
+//     the same for every slice), four ds_read2_b32 x-pairs, the lerps in the oracle's order.
 // No flags, no polling, no loader / consumer roles (round 2's kernel had all three and lost to them: its flag
-// protocol alone cost 1.2 ms per C3 frame, profiles/EXPERIMENTS.md part B section 4b).  Every voxel line of a tile's footprint is read
-// once per tile; neighbouring tiles overlap by the footprint's rim.
-//
+// protocol alone cost 1.2 ms per C3 frame), no page ring (round 3's: ~250 VALU per slice placed, in every wave).  This is
+// the fourth design (round 4: profiles/r04_sweep_v4.txt); like the three before it, it gives the oracle's frames and loses to
+// march_kernel: C3 in 2.2-3.9 ms against 1.0.
 // Reference-mode early ray termination (kernel.cu:272-274: one sample per later 30-sample chunk) would keep the
 // stream running for almost nothing, so once every live ray of the block has terminated -- or if a window ever
 // does not fit the ring -- the block stops copying and each wave finishes on direct gathers like march_kernel.
@@ -39,13 +42,13 @@ namespace sweepk {
 
 constexpr int kInf = 0x3fffffff;
 constexpr int kTfBytes = 4096;
-constexpr int kCtlBytes = 2048;
+constexpr int kCtlBytes = 1024;
 constexpr int kRingOff = kTfBytes + kCtlBytes;
 constexpr int kLdsMax = 160 * 1024;
-constexpr int kMaxChunks = 60;                 // rows (= LDS-DMA instructions) per slice image
-constexpr int kPage = 1024;                    // the ring is handed out in pages
-constexpr int kPages = (kLdsMax - kRingOff) / kPage;
-constexpr int kTab = 32;                       // slices the ring can hold at once (table entries)
+constexpr int kTab = 32;                       // table entries: the ring holds fewer slices than that (S.ring <= kTab - 2)
+constexpr int kCopyMax = 6;                    // LDS-DMA instructions a wave issues per slice at most (plan_sweep: units <= kCopyMax * 64 * waves)
+constexpr int kFxBits = 14;                    // fixed point of the window origins: slope error < ns / 2^14 voxels (plan_sweep: ns <= 4096)
+constexpr float kFxPad = 0.3f;                 // ... covered by this pad below the analytic bound
 
 typedef int __attribute__((ext_vector_type(4))) i4v;
 typedef int __attribute__((ext_vector_type(2))) i2v;
@@ -55,11 +58,11 @@ struct Ctl {                                   // control block in LDS
     int dmin, dmax;                            // extreme slopes of the block's rays, slices per step (float bits, -bits)
     int err;
     int anc[2][2];                             // double-buffered anchors: {min, -max} of the pending lanes' positions (offset float bits)
-    int still[3];                              // trip T, word T % 3: set by a wave that still needs the stream (no static LDS: the ring takes all 160 KB)
+    int still[3];                              // trip T, word T % 3: set by a wave that still needs the stream (no static LDS: the ring may take all 160 KB)
     int pad_[1];
-    i2v tab[kTab];                            // per slice k (entry k % kTab): byte address of voxel (x 0, row 0) of its image, row pitch
-    int box[kTab][4];                          // per slice: x0, x1, r0, r1 held (instrumented builds check against it)
-    int owner[kPages + 2];                     // per ring page: the slice whose image occupies it
+    int tab[kTab + 1];                         // per slice k (entry k % kTab; entry kTab repeats entry 0 so that a pair is one 8-byte read): byte address of voxel (x 0, row 0) of its image
+    int own[kTab];                             // instrumented builds: the slice whose image entry k % kTab describes
+    int box[kTab][4];                          // ... and x0, x1, r0, r1 it holds
 };
 static_assert(sizeof(Ctl) <= kCtlBytes, "control block");
 
@@ -118,16 +121,15 @@ __device__ __forceinline__ void lds_pairs(const char *a, const char *b, const ch
 // march).  That was harmless in round 2's kernel, whose copying waves never touched LDS otherwise, and is fatal here, where every
 // wave both copies and marches.  The ordering the algorithm needs is established explicitly: a counted `s_waitcnt vmcnt(N)`
 // (wait_vm_n) before the trip's barrier.  VMEM operations the compiler does not know about only make ITS counted waits stricter.
-__device__ __forceinline__ void lds_dma16(const void *gptr, const void *lds_ptr)
+__device__ __forceinline__ void lds_dma16(const void *gbase /* wave-uniform */, uint32_t goff, uint32_t lds_addr /* wave-uniform */)
 {
-    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)lds_ptr);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gptr), "s"(la) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(goff), "s"(gbase), "s"(lds_addr) : "memory");
 }
 // the trip's barrier: this wave's LDS writes done, then s_barrier (no `vmcnt(0)`: copies stay in flight across it)
 __device__ __forceinline__ void trip_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-// wait until at most n vector-memory operations of this wave are outstanding (n uniform, 0..kMaxChunks)
+// wait until at most n vector-memory operations of this wave are outstanding (n uniform)
 __device__ __forceinline__ void wait_vm_n(int n)
 {
     n = n > 63 ? 63 : n;                               // the counter has 6 bits; waiting for fewer is only stricter
@@ -141,7 +143,7 @@ __device__ __forceinline__ void wait_vm_n(int n)
     }
 }
 
-constexpr int kHist = 8;                       // trips the copies may run ahead of the march (S.ahead <= kHist)
+constexpr int kHist = 8;                       // S.ahead <= kHist
 constexpr int kAnchorTrips = 8;                // the block's extremes are re-anchored every so many trips
 constexpr float kWinMargin = 0.125f;           // slices; the affine position model is exact to ~1e-3
 constexpr float kPosOff = 4096.f;              // positions are offset so that their bit patterns order like integers (they can be < 0)
@@ -197,13 +199,14 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
         ctl->anc[0][0] = 0x7f800000; ctl->anc[0][1] = 0; ctl->anc[1][0] = 0x7f800000; ctl->anc[1][1] = 0;
         ctl->still[0] = 0; ctl->still[1] = 0; ctl->still[2] = 0;
     }
-    for (int i = threadIdx.x; i < kPages + 2; i += blockDim.x) ctl->owner[i] = -1;
+    if (INSTR) for (int i = threadIdx.x; i < kTab; i += blockDim.x) ctl->own[i] = -1;
     __syncthreads();
 
     const int nx = V.nx, nr = MAJOR == 2 ? V.ny : V.nz, ns = MAJOR == 2 ? V.nz : V.ny;
     // slice index s along the sweep axis -> position k in sweep order: s, or ns - s = (s ^ -1) + ns + 1
     const int kmul = S.sgn > 0 ? 1 : -1, kadd = S.sgn > 0 ? 0 : ns;
     const int kxor = S.sgn > 0 ? 0 : -1, kxadd = S.sgn > 0 ? 0 : ns + 1;
+    const int kpair = S.sgn > 0 ? 0 : -1;                  // slices `is` and `is + 1` sit at k0 + kpair and k0 + kpair + 1
     const float fns = (float)ns;
 
     // ---- this lane's ray ----
@@ -273,17 +276,44 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
     }
     int ring = (kmaxT >= kmin && Dmin <= Dmax && Dmax < 64.f) ? 1 : 0;        // block-uniform: the block streams slices through LDS
 
-    // ---- the copy side: frustum of the tile, deterministic ring layout ----
+    // ---- the copy side: frustum of the tile; the window of the tile in slice k is a closed form in scalars ----
+    // Every slice image is S.ry rows of S.pxw voxels (16-byte units, row pitch S.pxw * 4 bytes) in ring slot k mod S.ring; its origin
+    // follows the lower bounds of the tile's footprint, x0(k) = ((AX + MX * d) >> 14) & ~3 and r0(k) = (AR + MR * d) >> 14 with
+    // d = slice - first slice of the tile, clamped so that the image stays inside the volume's rows: integer arithmetic on wave-uniform
+    // values (SALU), the same in every wave, no allocation and no ownership table.  plan_sweep sizes pxw x ry for the widest footprint.
     Frustum F;
     tile_frustum<MAJOR>(P, V, min(x0, P.W - 1), min(y0, P.H - 1), min(x0 + tile_w - 1, P.W - 1), min(y0 + tile_h - 1, P.H - 1), F);
     FootLin FL;
     foot_linear(F, S.sgn > 0, FL);
-    const uint64_t Sr = MAJOR == 2 ? V.row_bytes : V.slice_bytes;       // bytes between rows of the image
-    const uint64_t Ss = MAJOR == 2 ? V.slice_bytes : V.row_bytes;       // bytes between slices
-    int issued_k = kmin - 1, head = 0;           // highest slice whose copies are issued; next free page (every wave: same values)
-    int cntH[kHist], hiH[kHist];                 // copies this wave issued 1 .. kHist trips ago, and the highest slice issued by the end of that trip
+    const uint32_t Sr = (uint32_t)(MAJOR == 2 ? V.row_bytes : V.slice_bytes);       // bytes between rows of the image
+    const uint64_t Ss = MAJOR == 2 ? V.slice_bytes : V.row_bytes;                   // bytes between slices
+    const int sl_ref = __builtin_amdgcn_readfirstlane(kmul * max(kmin, 0) + kadd);  // the tile's first slice
+    auto fx = [&](float a, float m) {           // bound(sl_ref) - pad, in fixed point (clamped: a tile that misses the volume streams nothing)
+        const float v = (__builtin_fmaf(m, (float)sl_ref, a) - kFxPad) * (float)(1 << kFxBits);
+        return __builtin_amdgcn_readfirstlane((int)fminf(fmaxf(floorf(v), -1.0e9f), 1.0e9f));
+    };
+    auto fm = [&](float m) {                    // slope, rounded so that slope * d never exceeds the analytic product (d >= 0 when slices grow along the sweep, else d <= 0)
+        const float v = fminf(fmaxf(m, -8.f), 8.f) * (float)(1 << kFxBits);
+        return __builtin_amdgcn_readfirstlane((int)(S.sgn > 0 ? floorf(v) : ceilf(v)));
+    };
+    const int AXi = fx(FL.ax_lo, FL.mx_lo), MXi = fm(FL.mx_lo), ARi = fx(FL.ar_lo, FL.mr_lo), MRi = fm(FL.mr_lo);
+    const int pitch = S.pxw * 4, upr = S.pxw >> 2, units = upr * S.ry;               // bytes per image row, 16-byte units per row / per image
+    // (a sample clamped to the last voxel / row reads its neighbour nx / nr with weight 0, axis_coord(): the image reaches one further,
+    //  into the next row / slice or the padding behind the volume, as the gather kernels' loads do)
+    const int x0_max = max(nx + 4 - S.pxw, 0), r0_max = max(nr + 1 - S.ry, 0);
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)lds);
+    // this lane's 16 bytes of an image: unit u = (wave + j NW) 64 + lane -> LDS byte 16 u (linear), global row u / upr, column u % upr
+    uint32_t goff[kCopyMax];
+    bool gval[kCopyMax];
+    int nq = 0;                                  // LDS-DMA instructions this wave issues per slice
 #pragma unroll
-    for (int h = 0; h < kHist; ++h) { cntH[h] = 0; hiH[h] = kmin - 1; }
+    for (int j = 0; j < kCopyMax; ++j) {
+        const int u = (wave + j * NW) * 64 + lane, row = u / upr;
+        gval[j] = u < units;
+        goff[j] = (uint32_t)row * Sr + (uint32_t)(u - row * upr) * 16u;
+        if ((wave + j * NW) * 64 < units) nq = j + 1;
+    }
+    int issued_k = kmin - 1, slot_next = 0;      // highest slice whose copies are issued; the ring slot of the next one (every wave: same values)
     unsigned long long staged = 0;
 
     // ---- march state (skewed lock step, as march_skew_kernel) ----
@@ -322,55 +352,31 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
             const float lo_prev = lo0 + (dt0 - (float)kU) * Dmin - kWinMargin;                       // the previous trip may still be computing
             const float hi_now = hi0 + (dt0 + (float)(kU - 1)) * Dmax + kWinMargin;
             const float hi_ahead = hi0 + (dt0 + (float)(kU - 1 + S.ahead * kU)) * Dmax + kWinMargin;
-            const int lo_free = max((int)floorf(lo_prev), kmin);                                   // slices below are read by nobody any more
-            const int need_hi = min((int)floorf(hi_now) + 1, kmaxT);
-            const int target = min(min((int)floorf(hi_ahead) + 1, kmaxT), lo_free + (kTab - 2));
-            int cnt0 = 0;
+            const int lo_free = __builtin_amdgcn_readfirstlane(max((int)floorf(lo_prev), kmin));                  // slices below are read by nobody any more
+            const int need_hi = __builtin_amdgcn_readfirstlane(min((int)floorf(hi_now) + 1, kmaxT));
+            const int target_w = min((int)floorf(hi_ahead) + 1, kmaxT);
             if (INSTR) tc0 = __builtin_readcyclecounter();
-            // (the `busy` test below reads ctl->owner[], which only wave 0 writes, and nothing orders that inside this loop: a trip must therefore never
-            //  place a slice on pages it handed out itself -- decided from scalars every wave holds identically: once the ring has wrapped in this trip,
-            //  allocations stop short of the trip's first page)
-            const int trip_first = head;
-            bool wrapped = false;
+            // slot k mod ring is free once slice k - ring lies below the window of the previous trip
+            const int target = __builtin_amdgcn_readfirstlane(min(target_w, lo_free + S.ring - 1));
             while (issued_k < target) {
-                const int k = issued_k + 1, sl = kmul * k + kadd;
-                Foot f = footprint(FL, sl, nx, nr);
-                f.x0 = __builtin_amdgcn_readfirstlane(f.x0); f.x1 = __builtin_amdgcn_readfirstlane(f.x1);
-                f.r0 = __builtin_amdgcn_readfirstlane(f.r0); f.r1 = __builtin_amdgcn_readfirstlane(f.r1);
-                const int c0 = f.x0 >> 5;
-                int ncell = (f.x1 >> 5) - c0 + 1, nrows = f.r1 - f.r0 + 1;
-                if (ncell > S.pxc || nrows > S.ry) { if (lane == 0) atomicOr(&ctl->err, 1 << 1); ncell = min(ncell, S.pxc); nrows = min(nrows, S.ry); }
-                const int pitch = ncell * 128, np = (nrows * pitch + kPage - 1) / kPage;
-                const bool wraps = !(head + np <= kPages);
-                const int pos = wraps ? 0 : head;
-                if ((wrapped || wraps) && pos + np > trip_first) break;        // would land on pages of this very trip: next trip
-                bool busy = false;
-                for (int b0 = 0; b0 < np; b0 += 64)
-                    if (b0 + lane < np) { const int ow = lds_load_i(&ctl->owner[pos + b0 + lane]); busy = busy || !(ow < lo_free || ow == k); }
-                if (any_(busy)) break;                                        // no room yet: next trip
-                const int img = kRingOff + pos * kPage;
-                if (wave == 0) {
-                    for (int b0 = 0; b0 < np; b0 += 64)
-                        if (b0 + lane < np) lds_store_i(&ctl->owner[pos + b0 + lane], k);
-                    if (lane == 0) {
-                        lds_store_i2(&ctl->tab[k & (kTab - 1)], i2v{img - f.r0 * pitch - c0 * 128, pitch});
-                        if (INSTR) { int *bx = ctl->box[k & (kTab - 1)]; bx[0] = c0 * 32; bx[1] = (c0 + ncell) * 32 - 1; bx[2] = f.r0; bx[3] = f.r0 + nrows - 1; }
-                    }
+                const int k = __builtin_amdgcn_readfirstlane(issued_k) + 1, sl = kmul * k + kadd, d = sl - sl_ref;    // (scalars for the compiler too)
+                const int sn = __builtin_amdgcn_readfirstlane(slot_next);
+                const int xo = min(max(((AXi + MXi * d) >> kFxBits) & ~3, 0), x0_max);
+                const int ro = min(max((ARi + MRi * d) >> kFxBits, 0), r0_max);
+                const int img = kRingOff + sn * S.slot_bytes;
+                if (threadIdx.x == 0) {
+                    const int e = img - ro * pitch - xo * 4;
+                    lds_store_i(&ctl->tab[k & (kTab - 1)], e);
+                    if ((k & (kTab - 1)) == 0) lds_store_i(&ctl->tab[kTab], e);
+                    if (INSTR) { int *bx = ctl->box[k & (kTab - 1)]; bx[0] = xo; bx[1] = xo + S.pxw - 1; bx[2] = ro; bx[3] = ro + S.ry - 1; ctl->own[k & (kTab - 1)] = k; }
                 }
-                // this wave's rows of the image: one LDS-DMA instruction per row, lane l copies bytes [16 l, 16 l + 16)
-                int rr = wave + k; rr -= (rr / NW) * NW;                      // rotate the rows over the waves from slice to slice
-                if (rr < nrows) {
-                    const char *gp = (const char *)V.data + (int64_t)sl * (int64_t)Ss + (uint64_t)(f.r0 + rr) * Sr + (uint64_t)c0 * 128u + (uint32_t)lane * 16u;
-                    int lb = img + rr * pitch;
-                    const uint64_t gstep = (uint64_t)NW * Sr;
-                    const int lstep = NW * pitch;
-                    for (; rr < nrows; rr += NW) {
-                        if (lane < 8 * ncell) lds_dma16(gp, lds + lb);
-                        gp += gstep; lb += lstep; ++cnt0;
-                    }
-                }
-                if (INSTR && wave == 0) staged += (unsigned long long)nrows * pitch;
-                head = __builtin_amdgcn_readfirstlane(pos + np); issued_k = k; wrapped = wrapped || wraps;
+                const char *gb = (const char *)V.data + (int64_t)sl * (int64_t)Ss + (uint64_t)(uint32_t)ro * (uint64_t)Sr + (uint64_t)(uint32_t)xo * 4u;
+                const uint32_t la = lds_base + (uint32_t)img + (uint32_t)wave * 1024u;
+#pragma unroll
+                for (int j = 0; j < kCopyMax; ++j)
+                    if (j < nq) { if (gval[j]) lds_dma16(gb, goff[j], la + (uint32_t)(j * NW) * 1024u); }
+                if (INSTR && wave == 0) staged += (unsigned long long)S.slot_bytes;
+                slot_next = sn + 1 == S.ring ? 0 : sn + 1; issued_k = k;
             }
             if (INSTR) { const unsigned long long tn = __builtin_readcyclecounter(); tc_issue += tn - tc0; tc0 = tn; }
             int bail = 0;
@@ -381,17 +387,9 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
                 bail = 1;
                 if (lane == 0) atomicOr(&ctl->err, 1 << 3);
             } else {
-                // wait for THIS wave's rows of the slices <= need_hi: everything but the copies issued after them
-                // (the copies issued in the trips AFTER the last one that had reached need_hi may stay in flight)
-                int nwait = 0, acc = cnt0;
-#pragma unroll
-                for (int h = 0; h < kHist; ++h) { if (hiH[h] >= need_hi) nwait = acc; acc += cntH[h]; }
-                wait_vm_n(__builtin_amdgcn_readfirstlane(nwait));             // (a scalar switch, not 64 exec-masked cases)
+                // wait for THIS wave's units of the slices <= need_hi: copies retire in order, nq per slice
+                wait_vm_n(__builtin_amdgcn_readfirstlane((issued_k - need_hi) * nq));
             }
-            cnt0 = __builtin_amdgcn_readfirstlane(cnt0);
-#pragma unroll
-            for (int h = kHist - 1; h > 0; --h) { cntH[h] = cntH[h - 1]; hiH[h] = hiH[h - 1]; }
-            cntH[0] = cnt0; hiH[0] = issued_k;
             // the one barrier of the trip: every wave's rows have landed; does any ray still need the stream?
             if (INSTR) { const unsigned long long tn = __builtin_readcyclecounter(); tc_wait += tn - tc0; tc0 = tn; }
             // (word trip % 3: written before this barrier, read after it, cleared two barriers before its next use)
@@ -471,12 +469,13 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
                 const bool inb = bounds_check(tx, ty, tz);
                 const int is = (int)(MAJOR == 2 ? iz : iy), ir = (int)(MAJOR == 2 ? iy : iz);
                 const int k0 = (is ^ kxor) + kxadd;              // position of slice `is`; slice is + 1 sits at k0 + kmul
-                const i2v T0 = lds_load_i2(&ctl->tab[k0 & (kTab - 1)]), T1 = lds_load_i2(&ctl->tab[(k0 + kmul) & (kTab - 1)]);
+                const i2v T = lds_load_i2(&ctl->tab[(k0 + kpair) & (kTab - 1)]);       // entries of slices `is` and `is + 1`: neighbours in the table
+                const int T0 = S.sgn > 0 ? T.x : T.y, T1 = S.sgn > 0 ? T.y : T.x;
                 const int x4 = (int)(ix << 2);
-                const char *p0 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)T0.y) + (T0.x + x4));
-                const char *p1 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)T1.y) + (T1.x + x4));
+                const char *p0 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)pitch) + (T0 + x4));
+                const char *p1 = lds + ((int)__umul24((uint32_t)ir, (uint32_t)pitch) + (T1 + x4));
                 float2u c00, c10, c01, c11;
-                lds_pairs(p0, p0 + T0.y, p1, p1 + T1.y, c00, c10, c01, c11);
+                lds_pairs(p0, p0 + pitch, p1, p1 + pitch, c00, c10, c01, c11);
                 // MAJOR == 2: rows are y, slices z.  MAJOR == 1: rows are z, slices y -- the lerp order stays x, y, z
                 const float2u a_ = c00, b_ = MAJOR == 2 ? c10 : c01, c_ = MAJOR == 2 ? c01 : c10, d_ = c11;
                 const float e00 = __builtin_fmaf(wx, a_.y - a_.x, a_.x);
@@ -493,7 +492,7 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
                     const bool okb = (int)ix >= bx0[0] && (int)ix + 1 <= bx0[1] && ir >= bx0[2] && ir + 1 <= bx0[3] &&
                                      (int)ix >= bx1[0] && (int)ix + 1 <= bx1[1] && ir >= bx1[2] && ir + 1 <= bx1[3];
                     // ... and both images must still be the ones of these slices (a page handed on too early would read as a miss)
-                    const int o0 = lds_load_i(&ctl->owner[(int)((p0 - lds) - kRingOff) >> 10]), o1 = lds_load_i(&ctl->owner[(int)((p1 - lds) - kRingOff) >> 10]);
+                    const int o0 = lds_load_i(&ctl->own[k0 & (kTab - 1)]), o1 = lds_load_i(&ctl->own[(k0 + kmul) & (kTab - 1)]);
                     if (!okb || o0 != k0 || o1 != k0 + kmul) ++misses;
                 }
             } else {
@@ -677,7 +676,8 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
     if (A.phong || A.V_type != VV_VOXEL_F32 || P.slice_type != SLICE_NONE) VV_NO("shaded, u8 or cutting plane");
     if (!P.alpha_unit) VV_NO("table opacities outside [0, 1]");       // the one-sample tail after early termination assumes monotone opacity
     if (P.ray_mode != VV_RAYS_ANALYTIC || P.quantize8) VV_NO("rays from images / quantised");
-    if ((V.row_bytes & 15u) || (V.slice_bytes & 15u) || ((uintptr_t)V.data & 15u)) VV_NO("rows not 16-byte aligned");
+    if ((V.row_bytes & 15u) || (V.slice_bytes & 15u) || ((uintptr_t)V.data & 15u) || (V.nx & 3)) VV_NO("rows not 16-byte aligned");
+    if (V.nx > 4096 || V.ny > 4096 || V.nz > 4096) VV_NO("more than 4096 slices");     // fixed-point window origins (kFxBits)
     if (!(P.step[0] == P.step[1] && P.step[1] == P.step[2])) VV_NO("anisotropic step");      // samples of a chunk must stay on the ray's line
     if (P.W < 2 || P.H < 2 || n_rows_px < 1) VV_NO("degenerate frame");
     const double n[3] = {(double)V.nx, (double)V.ny, (double)V.nz};
@@ -747,26 +747,34 @@ void plan_sweep(MarchArgs &A, int y_first, int n_rows_px, int own_bands)
         }
         const double slack = 2.0 * kMargin + 0.01;
         if (verbose) fprintf(stderr, "sweep: tile %dx%d waves: largest extent %.2f voxels in x, %.2f rows\n", S.wx, S.wy, ext_x, ext_r);
-        S.pxc = (int)floor((ext_x + slack + 2.0) / 32.0) + 2;
-        S.ry = (int)floor(ext_r + slack) + 3;
-        S.pxc = std::min(S.pxc, (V.nx + 31) / 32 + 1);
+        // The image of a slice: origin = fixed-point lower bound (at most one voxel below the analytic one: pad + slope error), x aligned
+        // down to 4 voxels (16-byte copies); it must reach the footprint's upper end: floor(hi) + 1 - (floor(lo) - 1 [- 3]) + 1 voxels.
+        S.pxw = (((int)floor(ext_x + slack) + 8) + 3) & ~3;
+        S.ry = (int)floor(ext_r + slack) + 4;
+        S.pxw = std::min(S.pxw, V.nx + 4);                                 // (voxel nx / row nr are read with weight 0: the device's x0_max, r0_max)
         S.ry = std::min(S.ry, nr + 1);
-        S.slot_bytes = S.pxc * 128 * S.ry;                               // the largest image of a slice
-        S.ring = (kPages * kPage) / S.slot_bytes;                        // slices of that size the ring holds (it holds more of the smaller ones)
-        // the block's window (~8-10 slices) + the slices in flight must fit; a forced shape may try its luck (a block whose window
-        // does not fit falls back to gathers by itself)
-        if (S.pxc <= 8 && S.ry <= kMaxChunks && S.ring >= (forced ? 6 : 10)) break;
+        S.pxc = (S.pxw * 4 + 127) / 128;                                  // (row pitch in 128-byte lines, for the record)
+        S.slot_bytes = S.pxw * 4 * S.ry;
+        // slices a trip reads (its steps + the trilinear neighbour + the skew of the tile's rays around the front) + one trip in flight
+        const double dzs = (double)P.step[best] * (double)P.inv_scale[best] * n[best];
+        const int need = (int)ceil(S.steps * dzs) + 4 + (int)ceil(S.steps * dzs);
+        // two blocks per CU when the ring still holds that, else one block with all of the LDS
+        int blocks = req.blocks >= 1 && req.blocks <= 4 ? req.blocks : 0;
+        if (!blocks) blocks = (kLdsMax / 2 - kRingOff) / S.slot_bytes >= need ? 2 : 1;
+        S.ring = std::min((kLdsMax / blocks - kRingOff) / S.slot_bytes, kTab - 2);
+        const int units = (S.pxw / 4) * S.ry;
+        if (S.ring >= (forced ? 4 : need) && units <= kCopyMax * 64 * S.nc) break;
         // footprint too large for the LDS (sparse pixels): smaller tiles, else no sweep
-        if (verbose) fprintf(stderr, "sweep: tile %dx%d waves needs pxc %d ry %d ring %d\n", S.wx, S.wy, S.pxc, S.ry, S.ring);
+        if (verbose) fprintf(stderr, "sweep: tile %dx%d waves needs %d x %d voxels per slice, ring %d of %d\n", S.wx, S.wy, S.pxw, S.ry, S.ring, need);
         if (forced) VV_NO("forced tile shape does not fit");
         if (S.wy > 2) S.wy -= 1; else if (S.wx > 1) { S.wx -= 1; S.wy = 4; } else VV_NO("footprint does not fit the LDS");
     }
     (void)nr;
     S.wmax = S.ring;
-    S.lds_bytes = kRingOff + kPages * kPage;
+    S.lds_bytes = kRingOff + S.ring * S.slot_bytes;
     S.order = nullptr; S.n_order = 0; S.trace = nullptr;
     S.enabled = 1;
-    if (verbose) fprintf(stderr, "sweep: axis %d sgn %d, tile %dx%d px (%d waves), image <= %d cells x %d rows (ring: %d of that size), %d steps per trip, %d trips ahead, %d x %d tiles\n", S.major, S.sgn, 32 * S.wx, 2 * S.wy, S.nc, S.pxc, S.ry, S.ring, S.steps, S.ahead, S.ntx, S.nty);
+    if (verbose) fprintf(stderr, "sweep: axis %d sgn %d, tile %dx%d px (%d waves), image %d voxels x %d rows (ring: %d slices, %d bytes of LDS), %d steps per trip, %d trips ahead, %d x %d tiles\n", S.major, S.sgn, 32 * S.wx, 2 * S.wy, S.nc, S.pxw, S.ry, S.ring, S.lds_bytes, S.steps, S.ahead, S.ntx, S.nty);
 #undef VV_NO
 }
 
