@@ -441,7 +441,7 @@ SWEEP_CAMS = {
 
 @pytest.mark.parametrize("view", list(SWEEP_CAMS))
 def test_sweep_kernel_is_bit_identical(xctx, view, monkeypatch):
-    """The slab sweep (vv_sweep.hip: volume streamed through an LDS slice ring by loader waves, VV_SWEEP=1
+    """The slab sweep (vv_sweep.hip: volume streamed through an LDS slice ring, every wave copies and marches; VV_SWEEP=1
     forces it wherever it qualifies) must give the oracle's frames and sample counts: both sweep axes and
     directions, ragged volume sizes, both ERT modes and filters, scaled cubes, sharded rows; the instrumented
     build also checks that no sample fell outside the slices' images in LDS and that no watchdog fired."""
