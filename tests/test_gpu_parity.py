@@ -77,11 +77,13 @@ def test_generator_edge_cases(ctx):
 
 
 def test_generator_rows_of_whole_waves(ctx):
-    """Rows of a multiple of 1024 voxels take ellipsoid_kernel's interval form (a wave = one row; whole chunks filled from their end voxels,
-    the two chunks at the interval's ends tested voxel by voxel by 32 helper lanes): the default brain and seeded random sets -- tiny
+    """Rows of a multiple of 1024 voxels take the interval form (a wave = one row segment; whole chunks filled from their end voxels, the two
+    chunks at the interval's ends tested voxel by voxel by 32 helper lanes) -- ellipsoid_rows_kernel (tables in LDS, tickets) for up to 8
+    ellipsoids and 1024 / 2048 / 4096 voxels per row, ellipsoid_kernel<true> otherwise: the default brain (also at sizes with several tickets
+    per block and a partial last round) and seeded random sets -- tiny
     ellipsoids inside one chunk, ellipsoids hanging over the volume's edges, zero and negative axes, more than 8 and more than 16 of
     them, overlapping in paint order -- against the oracle (= the compiled reference, tests/test_oracle.py), every byte."""
-    for dims in ((1024, 40, 24), (2048, 6, 5), (1024, 1, 1)):
+    for dims in ((1024, 40, 24), (2048, 6, 5), (1024, 1, 1), (1024, 160, 101), (2048, 64, 37)):
         assert np.array_equal(ctx.generate_default_brain(*dims), O.draw_default_brain(*dims)), dims
     rng = np.random.default_rng(20240)
     for case in range(24):

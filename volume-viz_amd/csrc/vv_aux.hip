@@ -353,6 +353,143 @@ __global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ ou
     }
 }
 
+// The rows-of-whole-waves form once more, for up to 8 ellipsoids whose x tables fit the LDS twice per CU (drawDefaultBrain at 1024^3: 39 KB,
+// at 2048^3: 78 KB).  ellipsoid_kernel<true> waits for memory once per row and twice per touching ellipsoid (tables that do not stay in the
+// 32 KB L1 beside the stores) and spends ~210 VALU instructions per row, 90 of them on index divisions and on testing all eight ellipsoids.
+// Here a block of 16 waves stages TX / TXS / TXE / TXM in LDS once; every wave then walks row segments (1024 voxels):
+//   * segments are handed out in tickets of 8 consecutive ones from an atomic counter (rows differ tenfold in cost: with a fixed share per
+//     wave the slowest of 8192 waves ends a third after the average one); the index arithmetic is scalar (a multiply-high for the division by ny);
+//   * a wave works on two segments at a time and has the row terms of its NEXT two already in flight: one 32-lane vector load (y terms in
+//     lanes 0..7 / 16..23, z terms in 8..15 / 24..31; a scalar load would be waited for by the first LDS read, they share a counter); the two
+//     16-byte stores per lane stay in flight across the wait for that load (`vmcnt(2)`);
+//   * which ellipsoids touch the row is one DPP add + compare + ballot; only those are visited (scalar bit loop), everything they need is LDS.
+// Same arithmetic, same order of ellipsoids (volumegenerator.cpp:51-63), same bytes.
+struct RowsArgs { uint32_t ny_magic; int ny_shift; int segs_log2; uint32_t rot; };      // q = mulhi(row, ny_magic) >> ny_shift (ny >= 2)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void ellipsoid_rows_kernel(uint8_t *__restrict__ out, int nx, int ny, int nz, int i_mark, const float *__restrict__ tab, EllipsoidColors E, RowsArgs A)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float gen_lds[];
+    const GenTables G(nx, ny, nz, E.n);
+    const int n = E.n, nx16 = G.nx16, nch = G.nch;             // (nx16 == nx: a multiple of 1024; G.n8 == 8)
+    float *LX = gen_lds, *LS = LX + (size_t)n * nx16, *LE = LS + (size_t)n * nch, *LM = LE + (size_t)n * nch;
+    char *patch = (char *)(LM + (size_t)n * nch) + (threadIdx.x >> 6) * 32;          // 2 x 16 bytes per wave (below)
+    uint32_t *ctr = (uint32_t *)((char *)(LM + (size_t)n * nch) + 16 * 32);           // the block's ticket counter
+    if (threadIdx.x == 0) *ctr = 0u;
+    for (int i = threadIdx.x * 4; i < n * nx16; i += blockDim.x * 4) *(float4 *)(LX + i) = *(const float4 *)(tab + i);
+    for (int i = threadIdx.x; i < 3 * n * nch; i += blockDim.x) LS[i] = tab[G.txs + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t rows = (uint32_t)ny * (uint32_t)nz, total = rows << A.segs_log2;                           // (generate_ellipsoids: < 2^31)
+    const int colv = lane < 8 && lane < n ? (int)E.color[lane] : 0;                                           // lane q: colour of ellipsoid q
+    const uint32_t ty_b = (uint32_t)G.ty * 4u, tz_b = (uint32_t)G.tz * 4u;
+    // lanes 0..7: the y terms of the segment's row for the 8 ellipsoids, lanes 8..15: the z terms
+    // the row terms of two segments in one load: lanes 0..7 the y terms of segment a's row for the 8 ellipsoids, 8..15 its z terms, 16..31 segment b's
+    const uint32_t lane4 = (uint32_t)(lane & 7) * 4u;
+    auto row_terms = [&](uint32_t sa_, uint32_t sb_ /* wave-uniform */) -> float {
+        const uint32_t sa = __builtin_amdgcn_readfirstlane(sa_), sb = __builtin_amdgcn_readfirstlane(sb_);     // (scalars for the compiler too)
+        const uint32_t ra = sa >> A.segs_log2, rb = sb >> A.segs_log2;
+        const uint32_t ka = ny > 1 ? __umulhi(ra, A.ny_magic) >> A.ny_shift : ra, ja = ra - ka * (uint32_t)ny;
+        const uint32_t kb = ny > 1 ? __umulhi(rb, A.ny_magic) >> A.ny_shift : rb, jb = rb - kb * (uint32_t)ny;
+        const uint32_t o0 = ty_b + ja * 32u, o1 = tz_b + ka * 32u, o2 = ty_b + jb * 32u, o3 = tz_b + kb * 32u;      // (scalars)
+        const uint32_t off = (lane < 16 ? (lane < 8 ? o0 : o1) : (lane < 24 ? o2 : o3)) + lane4;
+        return lane < 32 ? *(const float *)((const char *)tab + off) : 0.f;
+    };
+    // the marker slab (:85-87: x >= 0.99 after the last drawEllipsoid; n > 0 here) lies in the last segment of a row: this lane's byte masks there
+    uint32_t mk[4];
+    {
+        const int c0 = (((nx >> 10) - 1) * 64 + lane) * 16;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            mk[d] = 0u;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) if (c0 + 4 * d + v >= i_mark) mk[d] |= 0xffu << (8 * v);
+        }
+    }
+    const uint32_t last_seg = ((uint32_t)nx >> 10) - 1u;
+    // (a pair whose second segment does not exist -- odd total -- redoes the last one: the same bytes)
+    const uint32_t nmask = (1u << n) - 1u;
+    auto do_segment = [&](uint32_t sg /* scalar */, float cur, uint32_t touch /* scalar: bit q = ellipsoid q touches the row */, int lo /* lane of the row's y terms */) {
+        const uint32_t row = sg >> A.segs_log2, seg = sg - (row << A.segs_log2);
+        const int xc = (int)seg * 64 + lane, i0 = xc * 16;
+        uint32_t packed4[4] = {0u, 0u, 0u, 0u};                                    // ctor zero-fill :12-23
+        while (touch) {
+            const int q = __builtin_ctz(touch);
+            touch &= touch - 1u;
+            const float eyy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), lo + q));
+            const float ezz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), lo + 8 + q));
+            const uint32_t col4 = (uint32_t)__builtin_amdgcn_readlane(colv, q) * 0x01010101u;
+            const float xs = LS[q * nch + xc], xe = LE[q * nch + xc], xm = LM[q * nch + xc];
+            const bool fs = (xs + eyy) + ezz < 1.0f, fe = (xe + eyy) + ezz < 1.0f, fm = (xm + eyy) + ezz < 1.0f;
+            const bool full = fs && fe;
+            // (ballots of the plain comparisons: the compiler turns a ballot of `fm && !full` into two more vector instructions)
+            const unsigned long long bp = __builtin_amdgcn_ballot_w64(fm) & ~(__builtin_amdgcn_ballot_w64(fs) & __builtin_amdgcn_ballot_w64(fe));
+#pragma unroll
+            for (int d = 0; d < 4; ++d) packed4[d] = full ? col4 : packed4[d];
+            if (bp != 0ull) {
+                const int ca = __builtin_ctzll(bp);
+                const unsigned long long bp2 = bp & (bp - 1ull);
+                const int cb = bp2 ? __builtin_ctzll(bp2) : -1;
+                const int cg = lane < 16 ? ca : cb;
+                const bool helper = lane < 32 && cg >= 0;
+                const float xv = helper ? LX[q * nx16 + 16 * (xc - lane + cg) + (lane & 15)] : __builtin_inff();
+                const bool pv = helper && (xv + eyy) + ezz < 1.0f;                  // :57-59
+                // the owners of the two chunks park their 16 bytes in LDS, the helpers whose voxel is inside write its colour over them, the
+                // owners read the bytes back (LDS operations of one wave complete in order): 6 instructions instead of 24 for turning
+                // 2 x 16 ballot bits into byte masks
+                const bool own_b = lane == cb, own = lane == ca || own_b;
+                char *slot = patch + (own_b ? 16 : 0);
+                if (own) *(uint4 *)slot = make_uint4(packed4[0], packed4[1], packed4[2], packed4[3]);
+                if (pv) patch[lane] = (char)col4;
+                if (own) { const uint4 r = *(const uint4 *)slot; packed4[0] = r.x; packed4[1] = r.y; packed4[2] = r.z; packed4[3] = r.w; }
+            }
+        }
+        if (seg == last_seg) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) packed4[d] = (packed4[d] & ~mk[d]) | (0x04040404u & mk[d]);
+        }
+        uint8_t *rowp = out + (size_t)row * (size_t)nx;                               // scalar base + 32-bit lane offset
+        vv_gen_store16(rowp + (uint32_t)i0, make_uint4(packed4[0], packed4[1], packed4[2], packed4[3]));
+    };
+    // Work is handed out in tickets of 4 segment pairs (8 consecutive row segments).  Rows differ tenfold in cost, and with a fixed share per
+    // wave the slowest of 8192 waves ends a third after the average one (1024^3: 128 rows per wave).  A device-wide counter does not work either
+    // -- returning atomics on one address retire at ~12 ns each (measured: 131 072 tickets = 1.6 ms) -- so the split is in two levels: a block's
+    // share is fixed, its i-th ticket being i NB + ((b + i R) mod NB) with R ~ 0.618 NB (every block samples the whole volume; without the
+    // rotation block b would get the same rows of every slice), and the block's 16 waves draw i from a counter in LDS.  The next ticket is drawn
+    // when a ticket is started, and the row terms of its first pair are requested during the last pair of this one: neither wait is exposed.
+    const uint32_t pairs = (total + 1u) >> 1, all_tickets = (pairs + 3u) >> 2;
+    const uint32_t NB = gridDim.x, tickets = (all_tickets + NB - 1u) / NB;            // tickets per block (the last round may be short: clamped, redone)
+    auto ticket_of = [&](uint32_t i /* scalar */) -> uint32_t {                        // i < tickets: the block's i-th ticket; else >= all_tickets
+        const uint32_t r = (blockIdx.x + i * A.rot) % NB;                             // (once per 8 row segments)
+        return i < tickets ? min(i * NB + r, all_tickets - 1u) : all_tickets;
+    };
+    auto draw = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
+    auto terms_of_pair = [&](uint32_t pr) { return row_terms(min(2u * pr, total - 1u), min(2u * pr + 1u, total - 1u)); };
+    uint32_t ti = __builtin_amdgcn_readfirstlane(draw());                              // index of the ticket within the block's share
+    float pre = terms_of_pair(min(4u * min(ticket_of(ti), all_tickets - 1u), pairs - 1u));
+    asm volatile("" :: "v"(pre));                  // (landed before the loop)
+    while (ti < tickets) {
+        const uint32_t tks = __builtin_amdgcn_readfirstlane(ticket_of(__builtin_amdgcn_readfirstlane(ti)));   // (a scalar for the compiler too)
+        const uint32_t ti_next_v = draw();         // (lane 0; read three pairs later)
+#pragma unroll
+        for (uint32_t st = 0; st < 4u; ++st) {
+            const uint32_t pr = min(4u * tks + st, pairs - 1u);
+            const uint32_t sga = min(2u * pr, total - 1u), sgb = min(2u * pr + 1u, total - 1u);
+            const float cur = pre;
+            if (st < 3u) pre = terms_of_pair(min(4u * tks + st + 1u, pairs - 1u));
+            else {
+                ti = __builtin_amdgcn_readfirstlane(ti_next_v);
+                pre = terms_of_pair(min(4u * min(ticket_of(ti), all_tickets - 1u), pairs - 1u));      // (beyond the block's share: a valid address, never used)
+            }
+            // lanes q and 16 + q (q < 8): eyy + ezz of ellipsoid q for segment a / b (DPP row_shl:8 brings lane + 8's z term); the padding holds +inf
+            const float tsum = cur + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cur), 0x108, 0xf, 0xf, false));
+            const uint32_t tb = (uint32_t)__builtin_amdgcn_ballot_w64(tsum < 1.0f);      // else no voxel of the row is inside (ellipsoid_kernel)
+            do_segment(sga, cur, tb & nmask, 0);
+            do_segment(sgb, cur, (tb >> 16) & nmask, 16);
+        }
+    }
+}
+
 size_t generate_scratch_floats(int nx, int ny, int nz, int n)
 {
     return GenTables(nx, ny, nz, n).total + 16;
@@ -390,9 +527,31 @@ void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
     if (blocks > cap) blocks = cap;
     if (blocks == 0) return;
     // rows of whole waves (a multiple of 1024 voxels) of a fresh volume take the interval form
-    if (!in_place && n > 0 && xchunks % 64 == 0 && nx % 16 == 0)
+    if (!in_place && n > 0 && xchunks % 64 == 0 && nx % 16 == 0) {
+        // ... with the x tables in LDS when they fit it twice per CU (ellipsoid_rows_kernel)
+        const size_t lds = ((size_t)n * G.nx16 + 3 * (size_t)n * G.nch) * sizeof(float) + 16 * 32 + 16;      // tables + 32 bytes per wave + the ticket counter
+        static int rows_ok = -1;                       // the kernel's dynamic LDS limit, raised once
+        if (rows_ok < 0) rows_ok = hipFuncSetAttribute((const void *)ellipsoid_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 79 * 1024) == hipSuccess ? 1 : 0;
+        const size_t segments = (size_t)ny * nz * (nx / 1024);
+        const int segs = nx / 1024;
+        if (rows_ok == 1 && n <= 8 && lds <= 79u * 1024u && segments < (1ull << 28) && (segs & (segs - 1)) == 0 && !getenv("VV_GEN_NO_LDS")) {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            unsigned threads = 1024;
+            if (const char *e = getenv("VV_GEN_THREADS")) { const long v = atol(e); if (v == 256 || v == 512 || v == 1024) threads = (unsigned)v; }   // (experiment knob)
+            size_t nb = (size_t)cus * (2048 / threads);
+            if (nb > (segments + 15) / 16) nb = (segments + 15) / 16;
+            RowsArgs A;
+            int L = 0; while ((2u << L) <= (unsigned)ny) ++L;                          // floor(log2(ny))
+            A.ny_magic = ny > 1 ? (uint32_t)(((1ull << (31 + L)) + (uint64_t)ny - 1) / (uint64_t)ny) : 0u;   // exact for row < 2^28 (checked above)
+            A.ny_shift = L > 0 ? L - 1 : 0;
+            A.segs_log2 = 0; while ((1 << A.segs_log2) < segs) ++A.segs_log2;
+            A.rot = (uint32_t)(0.6180339887 * (double)nb) | 1u;                       // the rotation of a block's tickets (ellipsoid_rows_kernel)
+            hipLaunchKernelGGL(ellipsoid_rows_kernel, dim3((unsigned)nb), dim3(threads), lds, s, out, nx, ny, nz, i_mark, scratch, Cc, A);
+            return;
+        }
         hipLaunchKernelGGL(ellipsoid_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, out, nx, ny, nz, xchunks, i_mark, scratch, Cc, in_place);
-    else
+    } else
         hipLaunchKernelGGL(ellipsoid_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, out, nx, ny, nz, xchunks, i_mark, scratch, Cc, in_place);
 }
 
