@@ -527,7 +527,7 @@ def main():
                 gen["128^3"].update({"cpu_port_1thread_ms": round(d128 * 1e3, 1), "speedup": round(d128 * 1e3 / gen["128^3"]["hip_ms"], 1)})
                 gen["1024^3"].update({"cpu_port_1thread_ms_extrapolated": round(d16 * 64 * 1e3, 0), "speedup": round(d16 * 64 * 1e3 / gen["1024^3"]["hip_ms"], 0),
                                       "cpu_sample": f"16 slices of 1024 x 1024 voxels ({d16:.2f} s; every drawEllipsoid visits every voxel, so the cost per voxel does not depend on the slice) x 64"})
-            out["generator"] = {"what": "vv_generate_default_brain (8 ellipsoids fused, ellipsoid_kernel) into a device buffer; bound: VALU (profiles/r04_generator.txt), write roofline = HBM peak", **gen}
+            out["generator"] = {"what": "vv_generate_default_brain (8 ellipsoids fused; 1024^3: ellipsoid_rows_kernel, 128^3: ellipsoid_kernel = launch latency) into a device buffer; bound at 1024^3: VALU issue 68 % (profiles/r04_generator.txt), write roofline = HBM peak", **gen}
             cg.close()
         except Exception as e:
             out["generator"] = {"error": f"{type(e).__name__}: {e}"}
