@@ -560,6 +560,7 @@ def main():
                                  "1920x1080, step 1/2048, colour-ramp table, central-difference gradient + Phong, view a: march_phong_kernel (64-bit addressing build)",
                          "ms_per_frame": round(ms5, 4), "value": round(ns5 / ms5 / 1e3, 1), "unit": "Msamples/s", "executed_samples_per_frame": int(ns5),
                          "upload_seconds": round(up, 3), "upload_GB_per_s": round(n5 ** 3 / up / 1e9, 2),
+                         "upload_note": "includes this script's single-threaded host memcpy of every 128 MiB slab into the one pinned buffer (about two thirds of it); the library's streamer alone: tools/time_upload.py",
                          "roofline": {"bound": "hbm", "achieved": round(by5 / (ms5 * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                       "frac": round(by5 / (ms5 * 1e-3) / HBM_PEAK, 4), "traffic": None, "algorithmic_bytes_per_launch": int(by5)}}
             c5.close(); del fr5
