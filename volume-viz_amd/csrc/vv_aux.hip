@@ -365,30 +365,40 @@ __global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ ou
 //   * which ellipsoids touch the row is one DPP add + compare + ballot; only those are visited (scalar bit loop), everything they need is LDS.
 // Same arithmetic, same order of ellipsoids (volumegenerator.cpp:51-63), same bytes.
 struct RowsArgs { uint32_t ny_magic; int ny_shift; int segs_log2; uint32_t rot; };      // q = mulhi(row, ny_magic) >> ny_shift (ny >= 2)
+template <int SEGS_LOG2>                          // rows of 1024 << SEGS_LOG2 voxels
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void ellipsoid_rows_kernel(uint8_t *__restrict__ out, int nx, int ny, int nz, int i_mark, const float *__restrict__ tab, EllipsoidColors E, RowsArgs A)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float gen_lds[];
     const GenTables G(nx, ny, nz, E.n);
-    const int n = E.n, nx16 = G.nx16, nch = G.nch;             // (nx16 == nx: a multiple of 1024; G.n8 == 8)
-    float *LX = gen_lds, *LS = LX + (size_t)n * nx16, *LE = LS + (size_t)n * nch, *LM = LE + (size_t)n * nch;
-    char *patch = (char *)(LM + (size_t)n * nch) + (threadIdx.x >> 6) * 32;          // 2 x 16 bytes per wave (below)
-    uint32_t *ctr = (uint32_t *)((char *)(LM + (size_t)n * nch) + 16 * 32);           // the block's ticket counter
+    constexpr int nch = 64 << SEGS_LOG2, nx16 = 1024 << SEGS_LOG2;                   // (G.nch, G.nx16 == nx; G.n8 == 8)
+    const int n = E.n;
+    // the chunk terms of an ellipsoid side by side -- LC[q][0 / 1 / 2][chunk] = first-voxel / last-voxel / minimum term -- so that one vector
+    // address and three immediate offsets reach them
+    float *LX = gen_lds, *LC = LX + (size_t)n * nx16;
+    char *patch = (char *)(LC + (size_t)3 * n * nch) + (threadIdx.x >> 6) * 32;      // 2 x 16 bytes per wave (below)
+    uint32_t *ctr = (uint32_t *)((char *)(LC + (size_t)3 * n * nch) + 16 * 32);       // the block's ticket counter
     if (threadIdx.x == 0) *ctr = 0u;
+    // per wave: the row terms of its two current segments (32 floats) and the 8 colours (x 0x01010101), read back as LDS broadcasts: a value
+    // that reaches an add or a select through an SGPR (v_readlane) halves that instruction's issue rate (profiles/r04_instruction_rates.txt)
+    float *wterms = (float *)((char *)ctr + 16) + (threadIdx.x >> 6) * 40;
+    if ((threadIdx.x & 63) < 8) ((uint32_t *)wterms)[32 + (threadIdx.x & 63)] = (int)(threadIdx.x & 63) < n ? (uint32_t)E.color[threadIdx.x & 63] * 0x01010101u : 0u;
     for (int i = threadIdx.x * 4; i < n * nx16; i += blockDim.x * 4) *(float4 *)(LX + i) = *(const float4 *)(tab + i);
-    for (int i = threadIdx.x; i < 3 * n * nch; i += blockDim.x) LS[i] = tab[G.txs + i];
+    for (int i = threadIdx.x; i < 3 * n * nch; i += blockDim.x) {                    // tab: TXS[n][nch] TXE[n][nch] TXM[n][nch]
+        const int t = i / (n * nch), r = i - t * (n * nch), q = r / nch, c = r - q * nch;
+        LC[(q * 3 + t) * nch + c] = tab[G.txs + i];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const uint32_t rows = (uint32_t)ny * (uint32_t)nz, total = rows << A.segs_log2;                           // (generate_ellipsoids: < 2^31)
-    const int colv = lane < 8 && lane < n ? (int)E.color[lane] : 0;                                           // lane q: colour of ellipsoid q
+    const uint32_t rows = (uint32_t)ny * (uint32_t)nz, total = rows << SEGS_LOG2;                           // (generate_ellipsoids: < 2^31)
     const uint32_t ty_b = (uint32_t)G.ty * 4u, tz_b = (uint32_t)G.tz * 4u;
     // lanes 0..7: the y terms of the segment's row for the 8 ellipsoids, lanes 8..15: the z terms
     // the row terms of two segments in one load: lanes 0..7 the y terms of segment a's row for the 8 ellipsoids, 8..15 its z terms, 16..31 segment b's
     const uint32_t lane4 = (uint32_t)(lane & 7) * 4u;
     auto row_terms = [&](uint32_t sa_, uint32_t sb_ /* wave-uniform */) -> float {
         const uint32_t sa = __builtin_amdgcn_readfirstlane(sa_), sb = __builtin_amdgcn_readfirstlane(sb_);     // (scalars for the compiler too)
-        const uint32_t ra = sa >> A.segs_log2, rb = sb >> A.segs_log2;
+        const uint32_t ra = sa >> SEGS_LOG2, rb = sb >> SEGS_LOG2;
         const uint32_t ka = ny > 1 ? __umulhi(ra, A.ny_magic) >> A.ny_shift : ra, ja = ra - ka * (uint32_t)ny;
         const uint32_t kb = ny > 1 ? __umulhi(rb, A.ny_magic) >> A.ny_shift : rb, jb = rb - kb * (uint32_t)ny;
         const uint32_t o0 = ty_b + ja * 32u, o1 = tz_b + ka * 32u, o2 = ty_b + jb * 32u, o3 = tz_b + kb * 32u;      // (scalars)
@@ -410,16 +420,17 @@ void ellipsoid_rows_kernel(uint8_t *__restrict__ out, int nx, int ny, int nz, in
     // (a pair whose second segment does not exist -- odd total -- redoes the last one: the same bytes)
     const uint32_t nmask = (1u << n) - 1u;
     auto do_segment = [&](uint32_t sg /* scalar */, float cur, uint32_t touch /* scalar: bit q = ellipsoid q touches the row */, int lo /* lane of the row's y terms */) {
-        const uint32_t row = sg >> A.segs_log2, seg = sg - (row << A.segs_log2);
+        const uint32_t row = sg >> SEGS_LOG2, seg = sg - (row << SEGS_LOG2);
         const int xc = (int)seg * 64 + lane, i0 = xc * 16;
         uint32_t packed4[4] = {0u, 0u, 0u, 0u};                                    // ctor zero-fill :12-23
         while (touch) {
             const int q = __builtin_ctz(touch);
             touch &= touch - 1u;
-            const float eyy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), lo + q));
-            const float ezz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur), lo + 8 + q));
-            const uint32_t col4 = (uint32_t)__builtin_amdgcn_readlane(colv, q) * 0x01010101u;
-            const float xs = LS[q * nch + xc], xe = LE[q * nch + xc], xm = LM[q * nch + xc];
+            const float *wq = wterms + q;                                        // (one vector address, three broadcast reads)
+            const float eyy = wq[lo], ezz = wq[lo + 8];
+            const uint32_t col4 = ((const uint32_t *)wq)[32];
+            const float *lc = LC + q * (3 * nch) + xc;
+            const float xs = lc[0], xe = lc[nch], xm = lc[2 * nch];
             const bool fs = (xs + eyy) + ezz < 1.0f, fe = (xe + eyy) + ezz < 1.0f, fm = (xm + eyy) + ezz < 1.0f;
             const bool full = fs && fe;
             // (ballots of the plain comparisons: the compiler turns a ballot of `fm && !full` into two more vector instructions)
@@ -484,6 +495,7 @@ void ellipsoid_rows_kernel(uint8_t *__restrict__ out, int nx, int ny, int nz, in
             // lanes q and 16 + q (q < 8): eyy + ezz of ellipsoid q for segment a / b (DPP row_shl:8 brings lane + 8's z term); the padding holds +inf
             const float tsum = cur + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cur), 0x108, 0xf, 0xf, false));
             const uint32_t tb = (uint32_t)__builtin_amdgcn_ballot_w64(tsum < 1.0f);      // else no voxel of the row is inside (ellipsoid_kernel)
+            if (lane < 32) wterms[lane] = cur;                                          // (this wave's own reads follow in order)
             do_segment(sga, cur, tb & nmask, 0);
             do_segment(sgb, cur, (tb >> 16) & nmask, 16);
         }
@@ -529,12 +541,14 @@ void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
     // rows of whole waves (a multiple of 1024 voxels) of a fresh volume take the interval form
     if (!in_place && n > 0 && xchunks % 64 == 0 && nx % 16 == 0) {
         // ... with the x tables in LDS when they fit it twice per CU (ellipsoid_rows_kernel)
-        const size_t lds = ((size_t)n * G.nx16 + 3 * (size_t)n * G.nch) * sizeof(float) + 16 * 32 + 16;      // tables + 32 bytes per wave + the ticket counter
+        const size_t lds = ((size_t)n * G.nx16 + 3 * (size_t)n * G.nch) * sizeof(float) + 16 * 32 + 16 + 16 * 160;      // tables + 32 bytes per wave + the ticket counter + row terms and colours per wave
         static int rows_ok = -1;                       // the kernel's dynamic LDS limit, raised once
-        if (rows_ok < 0) rows_ok = hipFuncSetAttribute((const void *)ellipsoid_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 79 * 1024) == hipSuccess ? 1 : 0;
+        if (rows_ok < 0) rows_ok = hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+                                   hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+                                   hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess ? 1 : 0;
         const size_t segments = (size_t)ny * nz * (nx / 1024);
         const int segs = nx / 1024;
-        if (rows_ok == 1 && n <= 8 && lds <= 79u * 1024u && segments < (1ull << 28) && (segs & (segs - 1)) == 0 && !getenv("VV_GEN_NO_LDS")) {
+        if (rows_ok == 1 && n <= 8 && lds <= 80u * 1024u && segments < (1ull << 28) && (segs == 1 || segs == 2 || segs == 4) && !getenv("VV_GEN_NO_LDS")) {
             int dev = 0, cus = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             unsigned threads = 1024;
@@ -547,7 +561,9 @@ void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
             A.ny_shift = L > 0 ? L - 1 : 0;
             A.segs_log2 = 0; while ((1 << A.segs_log2) < segs) ++A.segs_log2;
             A.rot = (uint32_t)(0.6180339887 * (double)nb) | 1u;                       // the rotation of a block's tickets (ellipsoid_rows_kernel)
-            hipLaunchKernelGGL(ellipsoid_rows_kernel, dim3((unsigned)nb), dim3(threads), lds, s, out, nx, ny, nz, i_mark, scratch, Cc, A);
+            if (A.segs_log2 == 0) hipLaunchKernelGGL(ellipsoid_rows_kernel<0>, dim3((unsigned)nb), dim3(threads), lds, s, out, nx, ny, nz, i_mark, scratch, Cc, A);
+            else if (A.segs_log2 == 1) hipLaunchKernelGGL(ellipsoid_rows_kernel<1>, dim3((unsigned)nb), dim3(threads), lds, s, out, nx, ny, nz, i_mark, scratch, Cc, A);
+            else hipLaunchKernelGGL(ellipsoid_rows_kernel<2>, dim3((unsigned)nb), dim3(threads), lds, s, out, nx, ny, nz, i_mark, scratch, Cc, A);
             return;
         }
         hipLaunchKernelGGL(ellipsoid_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, out, nx, ny, nz, xchunks, i_mark, scratch, Cc, in_place);
