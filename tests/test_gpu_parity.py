@@ -103,6 +103,25 @@ def test_generator_rows_of_whole_waves(ctx):
         assert np.array_equal(got, want), f"case {case}: {nx}x{ny}x{nz}, {n} ellipsoids, kind {kind}: {int((got != want).sum())} voxels differ"
 
 
+def test_promote_is_the_ieee_quotient(ctx):
+    """vv_promote_device (u8 -> f32 as the reference's normalised-float texture read does, kernel.cu:46): promote_kernel forms b / 255 from a
+    product and two fused multiply-adds instead of a division; it must be the correctly rounded quotient for every byte, at every buffer size
+    (whole dwords, ragged tails, one voxel), and must not write past the end."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    for n in (1, 3, 4, 5, 255, 1023, 1024, 4099, 1 << 20, (1 << 20) + 7, 3 * (1 << 20) + 2):
+        v8 = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev)
+        if n >= 256:
+            v8[:256] = torch.arange(256, dtype=torch.uint8, device=dev)
+        v32 = torch.full((n + 8,), -7.0, dtype=torch.float32, device=dev)
+        ctx.promote_device(v8.data_ptr(), v32.data_ptr(), n)
+        torch.cuda.synchronize()
+        got = v32.cpu().numpy()
+        want = v8.cpu().numpy().astype(np.float32) / np.float32(255)
+        assert np.array_equal(got[:n].view(np.uint32), want.view(np.uint32)), n
+        assert (got[n:] == -7.0).all(), n
+
+
 def test_generator_large_matches_oracle_on_slabs(ctx):
     # 512^3 on the GPU; the oracle checks it through a size-independent property: every
     # z-slice of the N^3 brain depends only on fk = k/N, so slices at k = N/4, N/2 of the

@@ -574,27 +574,50 @@ void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
 // ---------------------------------------------------------------------------
 // u8 -> f32 promotion (v / 255), 16 voxels per thread
 // ---------------------------------------------------------------------------
+// b / 255.f for a byte b without the division: q0 = b * c, r = fma(-q0, 255, b), q = fma(r, c, q0) with c = fl(1 / 255) is the correctly
+// rounded quotient for every b in 0..255 (checked exhaustively against exact rational arithmetic): one conversion + three full-rate
+// instructions instead of a ~10-instruction IEEE division.
+__device__ __forceinline__ float byte_over_255(float b)
+{
+#pragma clang fp contract(off)
+    const float c = 1.0f / 255.0f;
+    const float q0 = b * c;
+    const float r = __builtin_fmaf(-q0, 255.0f, b);
+    return __builtin_fmaf(r, c, q0);
+}
+// One dword (4 voxels) per lane and trip: a wave reads 256 contiguous bytes and writes 1 KB contiguous (the first version converted 16 voxels
+// per lane: four stores of 16 bytes 64 bytes apart per lane, and sixteen divisions: 1.75 ms per GiB of voxels).
 __global__ __launch_bounds__(256) void promote_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, size_t n)
 {
-    const size_t nchunks = n / 16;
-    for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < nchunks; c += (size_t)gridDim.x * blockDim.x) {
-        uint4 p = *(const uint4 *)(in + c * 16);
-        const uint32_t w[4] = {p.x, p.y, p.z, p.w};
-        float4 *o = (float4 *)(out + c * 16);
+    const size_t nw = n / 4;
+    const uint32_t *in32 = (const uint32_t *)in;
+    float4 *out4 = (float4 *)out;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; c + 3 * stride < nw; c += 4 * stride) {           // four dwords in flight per lane
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = in32[c + q * stride];
+#pragma unroll
         for (int q = 0; q < 4; ++q)
-            o[q] = make_float4((float)(w[q] & 0xff) / 255.f, (float)((w[q] >> 8) & 0xff) / 255.f,
-                               (float)((w[q] >> 16) & 0xff) / 255.f, (float)(w[q] >> 24) / 255.f);
+            out4[c + q * stride] = make_float4(byte_over_255((float)(w[q] & 0xff)), byte_over_255((float)((w[q] >> 8) & 0xff)),
+                                               byte_over_255((float)((w[q] >> 16) & 0xff)), byte_over_255((float)(w[q] >> 24)));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 15)) {
-        size_t i = nchunks * 16 + threadIdx.x;
-        out[i] = (float)in[i] / 255.f;
+    for (; c < nw; c += stride) {
+        const uint32_t w = in32[c];
+        out4[c] = make_float4(byte_over_255((float)(w & 0xff)), byte_over_255((float)((w >> 8) & 0xff)),
+                              byte_over_255((float)((w >> 16) & 0xff)), byte_over_255((float)(w >> 24)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = nw * 4 + threadIdx.x;
+        out[i] = byte_over_255((float)in[i]);
     }
 }
 
 void launch_promote_u8_f32(const uint8_t *in, float *out, size_t n, hipStream_t s)
 {
-    size_t blocks = (n / 16 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(promote_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, out, n);
 }
