@@ -542,10 +542,23 @@ void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
     if (!in_place && n > 0 && xchunks % 64 == 0 && nx % 16 == 0) {
         // ... with the x tables in LDS when they fit it twice per CU (ellipsoid_rows_kernel)
         const size_t lds = ((size_t)n * G.nx16 + 3 * (size_t)n * G.nch) * sizeof(float) + 16 * 32 + 16 + 16 * 160;      // tables + 32 bytes per wave + the ticket counter + row terms and colours per wave
-        static int rows_ok = -1;                       // the kernel's dynamic LDS limit, raised once
-        if (rows_ok < 0) rows_ok = hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
-                                   hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
-                                   hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess ? 1 : 0;
+        // the kernel's dynamic LDS limit is raised once per device (a one-process multi-GPU host, include/volviz_mgpu.h, comes here with each of its devices)
+        static unsigned long long dev_ok = 0ull, dev_bad = 0ull;
+        int rows_ok = 0;
+        {
+            int dv = 0;
+            if (hipGetDevice(&dv) == hipSuccess && dv >= 0 && dv < 64) {
+                const unsigned long long bit = 1ull << dv;
+                if (!((dev_ok | dev_bad) & bit)) {
+                    const bool ok = hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+                                    hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+                                    hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+                    (void)hipGetLastError();
+                    (ok ? dev_ok : dev_bad) |= bit;
+                }
+                rows_ok = (dev_ok & bit) ? 1 : 0;
+            }
+        }
         const size_t segments = (size_t)ny * nz * (nx / 1024);
         const int segs = nx / 1024;
         if (rows_ok == 1 && n <= 8 && lds <= 80u * 1024u && segments < (1ull << 28) && (segs == 1 || segs == 2 || segs == 4) && !getenv("VV_GEN_NO_LDS")) {

@@ -571,14 +571,17 @@ __global__ __launch_bounds__(768) void sweep_kernel(FrameParams P, VolumeView V,
 template <class K>
 static bool sweep_launchable(K kern, size_t dynamic_bytes)
 {
-    static int static_lds = -2;                        // (one per instantiation: K is a distinct function type only per signature, so keyed below)
+    static int static_lds = -2;                        // (one per instantiation: K is a distinct function type only per signature, so keyed below -- and per device)
     static const void *keyed = nullptr;
-    if (keyed != (const void *)kern) {
+    static int keyed_dev = -1;
+    int dv = -1;
+    (void)hipGetDevice(&dv);
+    if (keyed != (const void *)kern || keyed_dev != dv) {
         hipFuncAttributes fa;
         static_lds = hipFuncGetAttributes(&fa, (const void *)kern) == hipSuccess ? (int)fa.sharedSizeBytes : -1;
         if (static_lds >= 0 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax - static_lds) != hipSuccess) static_lds = -1;
         (void)hipGetLastError();
-        keyed = (const void *)kern;
+        keyed = (const void *)kern; keyed_dev = dv;
     }
     return static_lds >= 0 && sweep_lds_fits((size_t)static_lds, dynamic_bytes);
 }
