@@ -357,12 +357,14 @@ __global__ __launch_bounds__(256) void ellipsoid_kernel(uint8_t *__restrict__ ou
 // at 2048^3: 78 KB).  ellipsoid_kernel<true> waits for memory once per row and twice per touching ellipsoid (tables that do not stay in the
 // 32 KB L1 beside the stores) and spends ~210 VALU instructions per row, 90 of them on index divisions and on testing all eight ellipsoids.
 // Here a block of 16 waves stages TX / TXS / TXE / TXM in LDS once; every wave then walks row segments (1024 voxels):
-//   * segments are handed out in tickets of 8 consecutive ones from an atomic counter (rows differ tenfold in cost: with a fixed share per
-//     wave the slowest of 8192 waves ends a third after the average one); the index arithmetic is scalar (a multiply-high for the division by ny);
+//   * segments are handed out in tickets of 8 consecutive ones: a block's share is fixed (rotated, so that every block samples the whole volume),
+//     its waves draw from a counter in LDS (rows differ tenfold in cost: with a fixed share per wave the slowest of 8192 waves ends a third
+//     after the average one; a device-wide counter retires one ticket per ~12 ns); the index arithmetic is scalar (a multiply-high for the division by ny);
 //   * a wave works on two segments at a time and has the row terms of its NEXT two already in flight: one 32-lane vector load (y terms in
 //     lanes 0..7 / 16..23, z terms in 8..15 / 24..31; a scalar load would be waited for by the first LDS read, they share a counter); the two
 //     16-byte stores per lane stay in flight across the wait for that load (`vmcnt(2)`);
-//   * which ellipsoids touch the row is one DPP add + compare + ballot; only those are visited (scalar bit loop), everything they need is LDS.
+//   * which ellipsoids touch the row is one DPP add + compare + ballot; only those are visited (scalar bit loop), everything they need is LDS --
+//     including the row terms and the colour, read back as broadcasts: an add or a select with an SGPR operand issues at 0.6 of the rate.
 // Same arithmetic, same order of ellipsoids (volumegenerator.cpp:51-63), same bytes.
 struct RowsArgs { uint32_t ny_magic; int ny_shift; int segs_log2; uint32_t rot; };      // q = mulhi(row, ny_magic) >> ny_shift (ny >= 2)
 template <int SEGS_LOG2>                          // rows of 1024 << SEGS_LOG2 voxels
