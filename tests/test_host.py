@@ -255,3 +255,38 @@ def test_developer_tools_parse():
                 if name.startswith(("VV_BENCH", "VV_GEN_")) or name in ("VV_EXPERIMENTAL", "VV_RAYS_IMAGES", "VV_RAYS_ANALYTIC"):
                     continue
                 assert name in known, f"{os.path.relpath(path, REPO)} uses {name}, which nothing reads"
+
+
+def test_byte_over_255_without_a_division_is_the_ieee_quotient():
+    """promote_kernel (csrc/vv_aux.hip: byte_over_255) forms b / 255 as q0 = fl(b c), r = fma(-q0, 255, b), q = fma(r, c, q0) with c = fl(1 / 255).
+    The claim that this is the correctly rounded binary32 quotient for every byte is checked here in exact rational arithmetic (the GPU test
+    test_promote_is_the_ieee_quotient checks the kernel itself against numpy's division)."""
+    from fractions import Fraction
+
+    def rn(fr):                                   # round a rational to binary32, ties to even
+        if fr == 0:
+            return Fraction(0)
+        sgn, a = (1 if fr > 0 else -1), abs(fr)
+        e = a.numerator.bit_length() - a.denominator.bit_length()
+        while Fraction(2) ** e > a: e -= 1
+        while Fraction(2) ** (e + 1) <= a: e += 1
+        ulp = Fraction(2) ** (e - 23)
+        k = a / ulp
+        kf = k.numerator // k.denominator
+        rem = k - kf
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and kf % 2 == 1):
+            kf += 1
+        return sgn * kf * ulp
+
+    c = rn(Fraction(1, 255))
+    assert float(c) == float(np.float32(1.0) / np.float32(255.0))
+    plain_wrong = 0
+    for b in range(256):
+        want = rn(Fraction(b, 255))
+        assert float(want) == float(np.float32(b) / np.float32(255.0)), b          # the rounding helper agrees with IEEE division
+        q0 = rn(b * c)
+        r = rn(b - q0 * 255)                      # fma: exact product and sum, one rounding
+        q = rn(q0 + r * c)
+        assert q == want, b
+        plain_wrong += q0 != want
+    assert plain_wrong > 100                      # (the plain product b * fl(1 / 255) is off by an ulp for about half the bytes)
