@@ -103,6 +103,18 @@ def test_generator_rows_of_whole_waves(ctx):
         assert np.array_equal(got, want), f"case {case}: {nx}x{ny}x{nz}, {n} ellipsoids, kind {kind}: {int((got != want).sum())} voxels differ"
 
 
+def test_generator_forms_agree(ctx, monkeypatch):
+    """The three forms of the fused generator give the same bytes: ellipsoid_rows_kernel (tables in LDS; rows of 1024 / 2048 voxels, <= 8
+    ellipsoids), ellipsoid_kernel<true> (the same rows without it: VV_GEN_NO_LDS=1) and the per-chunk form (in-place drawing takes it)."""
+    for dims in ((1024, 96, 53), (2048, 40, 21)):
+        a = ctx.generate_default_brain(*dims)
+        monkeypatch.setenv("VV_GEN_NO_LDS", "1")
+        b = ctx.generate_default_brain(*dims)
+        monkeypatch.delenv("VV_GEN_NO_LDS")
+        assert np.array_equal(a, b), dims
+        assert np.array_equal(a, O.draw_default_brain(*dims)), dims
+
+
 def test_promote_is_the_ieee_quotient(ctx):
     """vv_promote_device (u8 -> f32 as the reference's normalised-float texture read does, kernel.cu:46): promote_kernel forms b / 255 from a
     product and two fused multiply-adds instead of a division; it must be the correctly rounded quotient for every byte, at every buffer size
