@@ -378,6 +378,7 @@ def main():
         cam_b = vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5)
         for name, camera, phong, what, tkey in (
                 ("rotated_view", cam_b, False, "camera on the orbit r=4, theta=60 deg, phi=36 deg: march_kernel on the bricked copy", "c3-noise-ramp-b-n1"),
+                ("side_view", vv.Camera(origin=(-4.0, 0.0, 0.0)), False, "camera on the -x axis (screen x along the volume's z): march_kernel on the z-fastest copy", "c3-noise-ramp-side-n1"),
                 ("phong", cam, True, "view a with central-difference gradient + Phong: march_phong_kernel", "c3-noise-ramp-a-phong-n1")):
             try:
                 ns_x, by_x = instrumented(camera, phong)

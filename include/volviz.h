@@ -314,9 +314,9 @@ int  vv_t3d_write(const char *path, int header, const uint8_t *src, int nx, int 
  * Both are dropped when another volume is loaded; results never depend on which layout is sampled.
  * Returns the bit mask of the requested layouts that are resident afterwards (a layout that does
  * not fit in free HBM is skipped, not an error), or a negative vv_status.                     */
-enum { VV_LAYOUT_BRICKED = 1, VV_LAYOUT_ZPAIR = 2 };
+enum { VV_LAYOUT_BRICKED = 1, VV_LAYOUT_ZPAIR = 2, VV_LAYOUT_ZFAST = 4 /* f32: rows along z, for side views */ };
 int  vv_prepare_layouts(vv_context *ctx, int which, void *stream);
-/* Device memory held by the context: out[0] linear volume, [1] bricked copy, [2] z-pair copy,
+/* Device memory held by the context: out[0] linear volume, [1] bricked copy, [2] z-pair + z-fastest copies,
  * [3] tables and scratch (bytes). */
 int  vv_device_bytes(const vv_context *ctx, unsigned long long out[4]);
 

@@ -881,6 +881,52 @@ def test_zpair_copy_is_bit_identical(ctx, seed, monkeypatch):
     assert n_got == n and (ran or n == 0)
 
 
+@pytest.mark.parametrize("seed", range(2, 62, 3))
+def test_zfast_copy_is_bit_identical(ctx, seed, monkeypatch):
+    """The z-fastest copy of an f32 volume (rows along z: the front view's kernel for side views; VV_ZFAST=1 forces it for every unshaded
+    frame whose screen x does not run along the volume's x) on the random sweep's cases: any view, ragged sizes, cutting planes, shards.
+    u8 volumes and shaded frames keep their layouts."""
+    monkeypatch.setenv("VV_ZFAST", "1")
+    vol, tf, W, H, cam, sp, phong, o = _random_case(seed)
+    if seed % 2 == 0 and vol.dtype != np.float32:
+        vol = vol.astype(np.float32) / np.float32(255)
+    ctx.load_volume(vol, tf)
+    opts = vv.make_options(**o)
+    got = ctx.render(W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
+    n_got = ctx.last_sample_count()
+    lay = ctx.last_launch()
+    want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
+    assert_frames_close(got, want, f"zfast seed {seed}: {vol.shape} {vol.dtype} phong={phong} layout {lay['layout']}")
+    assert n_got == n
+    if vol.dtype != np.float32 or phong:
+        assert lay["layout"] != 4
+
+
+def test_zfast_side_views(ctx, monkeypatch):
+    """Side views (camera on the x axis, either side, tilted a little) of f32 volumes through the z-fastest copy: the policy picks it for
+    volumes beyond the caches only, so it is forced here; edge sizes; the copy is accounted for and dropped with the volume."""
+    monkeypatch.setenv("VV_ZFAST", "1")
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    rng = np.random.default_rng(11)
+    took = 0
+    for k, dims in enumerate(((1, 1, 1), (3, 1, 2), (5, 4, 3), (17, 16, 15), (2, 9, 33), (64, 48, 40), (256, 7, 258))):
+        vol = (rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)).astype(np.float32) / np.float32(255)
+        ctx.load_volume(vol, tf)
+        for cam in (vv.Camera(origin=(4.0, 0.0, 0.0)), vv.Camera(origin=(-3.5, 0.3, 0.2)), vv.Camera(origin=(3.8, -0.4, 0.5))):
+            for ert, filt in ((vv.ERT_REFERENCE, vv.FILTER_TEX8), (vv.ERT_TRUE, vv.FILTER_EXACT)):
+                o = dict(step=1 / 40, ert_mode=ert, ert_threshold=0.9, filter=filt)
+                got = ctx.render(97, 61, cam, options=vv.make_options(count_samples=True, **o))
+                n_got = ctx.last_sample_count()
+                took += ctx.last_launch()["layout"] == 4
+                want, n = O.render(vol, tf, 97, 61, cam, options=vv.make_options(**o))
+                assert_frames_close(got, want, f"zfast side view {dims} {cam.origin} ert{ert} filt{filt}")
+                assert n_got == n
+        assert ctx.device_bytes()[2] > 0
+    assert took >= 36, took
+    ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
+    assert ctx.device_bytes()[2] == 0
+
+
 def test_zpair_default_policy_and_edges(ctx, monkeypatch):
     """Default policy: an aligned, unshaded view samples the z-pair copy (both voxel types); edge sizes."""
     monkeypatch.delenv("VV_ZPAIR", raising=False)
@@ -1057,11 +1103,14 @@ def test_c3_headline_frames_match_oracle(ctx):
     del v8, v32
     torch.cuda.empty_cache()
     threads = min(len(os.sched_getaffinity(0)), 16)
-    for cam, phong, slot in ((vv.Camera(), False, None), (vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5), False, 2), (vv.Camera(), True, None)):
+    for cam, phong, slot in ((vv.Camera(), False, None), (vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5), False, 2), (vv.Camera(), True, None),
+                             (vv.Camera(origin=(-4.0, 0.2, 0.1)), False, "zfast")):        # (the last: a side view, through the z-fastest copy by policy)
         opts = vv.make_options(step=1 / 512, count_samples=True)
         got = ctx.render(W, H, cam, phong=phong, options=opts)
         n_got = ctx.last_sample_count()
-        if slot is not None:
+        if slot == "zfast":
+            assert ctx.last_launch()["layout"] == 4
+        elif slot is not None:
             assert ctx.debug_counters()[slot] > 0
         want, n_want = O.render(host, tf, W, H, cam, phong=phong, options=vv.make_options(step=1 / 512), threads=threads)
         assert_frames_close(got, want, f"C3 frame phong={phong} layout={slot}")

@@ -14,7 +14,8 @@ sys.path.insert(0, REPO)
 os.environ.setdefault("TMPDIR", "/tmp")
 os.environ["VV_BENCH_NO_EXTRA"] = "1"
 OUT = os.path.join(REPO, "gpurun_out", "pmc_traffic")
-CONFIGS = {"c3-noise-ramp-a-n1": ["--view", "a"], "c3-noise-ramp-b-n1": ["--view", "b"], "c3-noise-ramp-a-phong-n1": ["--view", "a", "--phong"]}
+CONFIGS = {"c3-noise-ramp-a-n1": ["--view", "a"], "c3-noise-ramp-b-n1": ["--view", "b"], "c3-noise-ramp-a-phong-n1": ["--view", "a", "--phong"],
+           "c3-noise-ramp-side-n1": ["--orbit", "90,180"]}
 N = 1024
 
 

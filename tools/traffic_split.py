@@ -29,7 +29,7 @@ import volviz_amd as vv
 
 # (every name here is read by vv_knobs::read(); a variant that sets another VV_* name is refused below)
 KNOBS = ("VV_XCD_BAND", "VV_LDS_RESERVE", "VV_UNROLL", "VV_TILE_LOG2W", "VV_SWEEP", "VV_SKEW",
-         "VV_SWEEP_WX", "VV_SWEEP_WY", "VV_SWEEP_AHEAD", "VV_SWEEP_STEPS", "VV_LDS_RESERVE_PHONG", "VV_BRICKED", "VV_ZPAIR", "VV_BLOCK_W", "VV_TAIL", "VV_PHONG2", "VV_PHONG_PAIR")
+         "VV_SWEEP_WX", "VV_SWEEP_WY", "VV_SWEEP_AHEAD", "VV_SWEEP_STEPS", "VV_LDS_RESERVE_PHONG", "VV_BRICKED", "VV_ZPAIR", "VV_BLOCK_W", "VV_TAIL", "VV_PHONG2", "VV_PHONG_PAIR", "VV_ZFAST")
 
 # name, env, slab_rows (None = whole frame), extra
 VARIANTS = [

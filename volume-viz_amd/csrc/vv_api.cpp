@@ -22,7 +22,7 @@ using namespace vv;
 // volume load -- never on the per-frame path.
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
-    int bricked = -1, zpair = -1, sweep = -1, sweep_trace = 0, force_big = 0;
+    int bricked = -1, zpair = -1, zfast = -1, sweep = -1, sweep_trace = 0, force_big = 0;
     int skew = -1, block_w = -1, tail = -1, phong2 = -1, phong_pair = -1;
     int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_blocks = -1, sw_verbose = 0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
@@ -34,7 +34,7 @@ struct vv_knobs {
         skew = geti("VV_SKEW", -1); block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1); phong2 = geti("VV_PHONG2", -1); phong_pair = geti("VV_PHONG_PAIR", -1);
         sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1); sw_blocks = geti("VV_SWEEP_BLOCKS", -1);
         sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
-        sweep = geti("VV_SWEEP", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
+        sweep = geti("VV_SWEEP", -1); zfast = geti("VV_ZFAST", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
     }
 };
 
@@ -51,6 +51,7 @@ struct vv_context {
     void *d_bricks = nullptr; bool bricks_valid = false, bricks_failed = false; uint32_t b_sy = 0, b_sz64 = 0; size_t bricks_bytes = 0;
     // z-pair copy of an f32 volume for views along the memory axis (same life cycle)
     void *d_zpair = nullptr; bool zpair_valid = false; uint32_t zp_row = 0, zp_slab = 0; size_t zpair_bytes = 0;
+    void *d_zfast = nullptr; bool zfast_valid = false, zfast_failed = false; uint32_t zf_row = 0; uint64_t zf_slice = 0; size_t zfast_bytes = 0;   // z-fastest copy (f32, side views)
     // transfer function
     float4 *d_tf = nullptr; bool tf_gray = false; bool have_tf = false;
     bool tf_alpha_unit = false;          // every opacity of the table lies in [0, 1]: accumulated opacity never decreases
@@ -102,6 +103,8 @@ static void drop_bricks(vv_context *c)
     c->d_bricks = nullptr; c->bricks_valid = false; c->bricks_failed = false; c->bricks_bytes = 0;
     if (c->d_zpair) (void)hipFree(c->d_zpair);
     c->d_zpair = nullptr; c->zpair_valid = false; c->zpair_bytes = 0;
+    if (c->d_zfast) (void)hipFree(c->d_zfast);
+    c->d_zfast = nullptr; c->zfast_valid = false; c->zfast_failed = false; c->zfast_bytes = 0;
 }
 
 static int ensure(vv_context *c, void **p, size_t *cap, size_t need)
@@ -166,6 +169,7 @@ static bool estimate_view_from_images(const uint8_t *front, const uint8_t *back,
 }
 static bool ensure_bricks(vv_context *c, hipStream_t st);
 static bool ensure_zpair(vv_context *c, hipStream_t st);
+static bool ensure_zfast(vv_context *c, hipStream_t st);
 
 extern "C" {
 
@@ -304,6 +308,7 @@ int vv_prepare_layouts(vv_context *c, int which, void *stream)
     if (which & VV_LAYOUT_BRICKED) c->bricks_failed = false;       // an explicit request retries after an earlier shortage of HBM
     if ((which & VV_LAYOUT_BRICKED) && ensure_bricks(c, st)) built |= VV_LAYOUT_BRICKED;
     if ((which & VV_LAYOUT_ZPAIR) && ensure_zpair(c, st)) built |= VV_LAYOUT_ZPAIR;
+    if ((which & VV_LAYOUT_ZFAST) && ensure_zfast(c, st)) built |= VV_LAYOUT_ZFAST;
     return built;
 }
 
@@ -378,7 +383,7 @@ int vv_device_bytes(const vv_context *c, unsigned long long out[4])
     if (!c || !out) return VV_ERR_INVALID;
     out[0] = c->d_vol ? c->alloc_bytes : 0;
     out[1] = c->bricks_valid ? c->bricks_bytes : 0;
-    out[2] = c->zpair_valid ? c->zpair_bytes : 0;
+    out[2] = (c->zpair_valid ? c->zpair_bytes : 0) + (c->zfast_valid ? c->zfast_bytes : 0);
     out[3] = c->rad_cap + c->frame_cap + c->img_cap + c->slice_cap + 4096 + 8 * sizeof(unsigned long long);
     return VV_OK;
 }
@@ -638,6 +643,33 @@ static bool ensure_zpair(vv_context *c, hipStream_t st)
     return true;
 }
 
+// The z-fastest copy of an f32 volume (VolumeView::zfast): rows of nz voxels padded like the linear layout's rows (finalize_layout),
+// ny rows per slice, nx slices + one slice, one row and 16 bytes of zeros behind them (the weight-0 corners of edge samples).
+static bool ensure_zfast(vv_context *c, hipStream_t st)
+{
+    if (c->zfast_valid) return true;
+    if (c->zfast_failed || c->vtype != VV_VOXEL_F32) return false;
+    size_t row = (size_t)c->nz * 4;
+    if (row % 1024 == 0) row += 32;
+    size_t rows = (size_t)c->ny;
+    if (row != (size_t)c->nz * 4 && (rows * row) % 4096 == 0) rows += 1;
+    const size_t slice = rows * row, bytes = slice * ((size_t)c->nx + 1) + row + 16;
+    size_t free_b = 0, total_b = 0;
+    if (row >= (1u << 24) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (512ull << 20) ||
+        hipMalloc(&c->d_zfast, bytes) != hipSuccess) {
+        (void)hipGetLastError(); c->d_zfast = nullptr; c->zfast_failed = true;
+        return false;                                                     // no room: the bricked copy serves the view
+    }
+    if (hipMemsetAsync(c->d_zfast, 0, bytes, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(c->d_zfast); c->d_zfast = nullptr; c->zfast_failed = true; return false; }
+    launch_build_zfast((const float *)c->d_vol, (uint32_t)c->row_pitch, (uint64_t)c->slice_pitch, (float *)c->d_zfast, (uint32_t)row, (uint64_t)slice, c->nx, c->ny, c->nz, st);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {      // later frames may come on another stream
+        (void)hipGetLastError(); (void)hipFree(c->d_zfast); c->d_zfast = nullptr; c->zfast_failed = true;
+        return false;
+    }
+    c->zf_row = (uint32_t)row; c->zf_slice = (uint64_t)slice; c->zfast_bytes = bytes; c->zfast_valid = true;
+    return true;
+}
+
 static VolumeView view_of(const vv_context *c)
 {
     VolumeView V;
@@ -649,6 +681,7 @@ static VolumeView view_of(const vv_context *c)
     V.big = c->slice_pitch * (size_t)c->nz > (1ull << 32) || V.slice_bytes >= (1u << 24) || c->knobs.force_big;
     V.bricks = nullptr; V.b_sy = 0; V.b_sz64 = 0;
     V.zpair = nullptr; V.zp_row_bytes = 0; V.zp_slab_bytes = 0;
+    V.zfast = nullptr; V.zf_row_bytes = 0; V.zf_slice_bytes = 0;
     return V;
 }
 
@@ -840,7 +873,21 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         if (ax >= 0.97f * sqrtf(ax * ax + ay * ay + az * az)) A.strips.tile_log2w = 5;
     }
     const vv_knobs &K = c->knobs;
-    if (K.tile_log2w >= 3 && K.tile_log2w <= 5) A.strips.tile_log2w = K.tile_log2w;
+    // z-fastest copy (speed only): when the screen x direction maps onto the volume's z axis (side views) the same 32 x 2 tile reads whole
+    // lines of a copy whose rows run along z -- the front view's kernel and time instead of the bricked copy's (1.5 -> 1.0 ms on C3).  f32
+    // volumes beyond the caches, unshaded frames, built on first use if HBM has room (one more copy of the volume).  VV_ZFAST=0/1 overrides.
+    bool use_zfast = false;
+    if (have_basis && A.strips.tile_log2w == 3 && c->vtype == VV_VOXEL_F32 && !shading->phongShading) {
+        const float ax = fabsf(P.side[0]) , ay = fabsf(P.side[1]), az = fabsf(P.side[2]);
+        use_zfast = az >= 0.97f * sqrtf(ax * ax + ay * ay + az * az) && c->vol_bytes > (1ull << 30);
+        if (K.zfast >= 0) use_zfast = K.zfast != 0;
+    }
+    if (use_zfast) use_zfast = ensure_zfast(c, st);
+    if (use_zfast) {
+        A.strips.tile_log2w = 5;
+        A.V.zfast = c->d_zfast; A.V.zf_row_bytes = c->zf_row; A.V.zf_slice_bytes = c->zf_slice;
+    }
+    if (K.tile_log2w >= 3 && K.tile_log2w <= 5 && !use_zfast) A.strips.tile_log2w = K.tile_log2w;
     // Occupancy cap + gathers in flight (speed only; measured on MI355X, profiles/EXPERIMENTS.md part B section 4):
     //   volume beyond the caches (> 1 GiB), aligned view : 2 blocks per CU, 3 samples per trip
     //   volume beyond the caches, rotated, linear layout : 1 block  per CU, 3 samples per trip
@@ -913,6 +960,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // only volumes far below the frame's sampling density lose (64^3 at 1080p, step 1/512: +10 %).
     bool use_bricks = A.strips.tile_log2w == 3 && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
     if (K.bricked >= 0) use_bricks = K.bricked != 0;
+    if (use_zfast) use_bricks = false;
     if (use_bricks) use_bricks = ensure_bricks(c, st);
     if (use_bricks) {
         A.V.bricks = c->d_bricks; A.V.b_sy = c->b_sy; A.V.b_sz64 = c->b_sz64;
@@ -930,6 +978,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     bool use_zpair = !use_bricks && A.strips.tile_log2w == 5 && !shading->phongShading &&
                      (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20));
     if (K.zpair >= 0) use_zpair = K.zpair != 0 && !use_bricks;
+    if (use_zfast) use_zpair = false;
     if (use_zpair) use_zpair = ensure_zpair(c, st);
     if (use_zpair) { A.V.zpair = c->d_zpair; A.V.zp_row_bytes = c->zp_row; A.V.zp_slab_bytes = c->zp_slab; }
     // Phong kernel: 14.3 KB of LDS per block + this reserve.  Measured (tools/ab_phong.sh): volumes up to
@@ -966,7 +1015,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), st));
     c->counter_valid = A.instr; c->sweep_err_valid = false;
     {
-        const int layout = A.V.bricks ? 2 : (A.V.zpair ? 3 : ((A.V.big || (A.phong && beyond_caches)) ? 1 : 0));
+        const int layout = A.V.zfast ? 4 : (A.V.bricks ? 2 : (A.V.zpair ? 3 : ((A.V.big || (A.phong && beyond_caches)) ? 1 : 0)));
         const int v[8] = {A.strips.tile_log2w, A.strips.blk_log2w, A.unroll, A.phong ? A.lds_reserve_phong : A.lds_reserve, layout, have_basis ? 1 : 0,
                           (int)fminf(density * 1000.f, 2e9f), A.phong ? 1 : 0};
         memcpy(c->last_launch, v, sizeof v);
@@ -976,7 +1025,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (A.phong) {
         // (linear volumes beyond the caches take the 64-bit-addressing build even below 4 GiB: the other one is compiled for 5 waves per SIMD, which only
         //  cache-resident volumes want -- 1000^3 f32: 1.884 -> 1.817 ms, tools/ab_env.sh VV_FORCE_BIG=1)
-        if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); } else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big || beyond_caches) launch_raymarch_big(A, st); else launch_raymarch(A, st);
+        if (A.V.zfast) launch_raymarch_zfast(A, st); else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); } else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big || beyond_caches) launch_raymarch_big(A, st); else launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
         bool sweep = false;
@@ -1004,6 +1053,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         }
 #endif
         if (sweep) { }
+        else if (A.V.zfast) launch_raymarch_zfast(A, st);
         else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); }
         else if (A.V.zpair) launch_raymarch_zpair(A, st);
         else if (A.V.big) launch_raymarch_big(A, st);

@@ -56,6 +56,12 @@ struct VolumeView {
     const void *zpair;
     uint32_t zp_row_bytes;  // (nx+1) records, u8 rows rounded up to 4 bytes
     uint32_t zp_slab_bytes; // (ny+1) * zp_row_bytes
+    // Optional z-fastest copy of an f32 volume for views whose screen x runs along the volume's z axis (side views; built on first use):
+    // voxel (x, y, z) at zfast + x * zf_slice_bytes + y * zf_row_bytes + 4 z, padded like the linear layout.  The lanes of a wave tile then
+    // read consecutive z, as they read consecutive x of the linear layout in a front view: the same kernel, the same time.
+    const void *zfast;
+    uint32_t zf_row_bytes;  // nz * 4 (+ padding)
+    uint64_t zf_slice_bytes; // ny * zf_row_bytes
 };
 template <int VOXEL> struct BrickGeom;
 #ifndef VV_BRICK_XLOG2
@@ -70,7 +76,7 @@ template <int VOXEL> struct BrickGeom;
 template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t xlog2 = VV_BRICK_XLOG2, bx = 1u << xlog2, halo = VV_BRICK_HALO, row = (bx + halo) * 4,
                                              zlog2 = VV_BRICK_ZLOG2, bz = 1u << zlog2, rows = 4 * bz, brick = rows * row; };
 template <> struct BrickGeom<VV_VOXEL_U8>  { static constexpr uint32_t xlog2 = 2, bx = 4, row = 8, zlog2 = 2, bz = 4, rows = 16, brick = 128; };
-enum { LAYOUT_LINEAR = 0, LAYOUT_LINEAR_BIG = 1, LAYOUT_BRICKED = 2, LAYOUT_ZPAIR = 3 };
+enum { LAYOUT_LINEAR = 0, LAYOUT_LINEAR_BIG = 1, LAYOUT_BRICKED = 2, LAYOUT_ZPAIR = 3, LAYOUT_ZFAST = 4 };
 
 // Everything a frame needs that is uniform over the launch.
 struct FrameParams {
@@ -326,7 +332,7 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
         // up to 4 GiB: one 32-bit byte offset per sample added to four scalar bases (saddr + voffset)
         load_rows<VOXEL>((const char *)V.data, V.row_bytes, V.slice_bytes, ix,
                          __umul24(iy, V.row_bytes) + __umul24(iz, V.slice_bytes), C);
-    } else if constexpr (LAYOUT == LAYOUT_LINEAR_BIG) {
+    } else if constexpr (LAYOUT == LAYOUT_LINEAR_BIG || (LAYOUT == LAYOUT_ZFAST && VOXEL != VV_VOXEL_F32)) {      // (the z-fastest build's u8 kernels are never launched on that copy)
         // volumes above 4 GiB (separate kernel instantiations): one 64-bit address per lane for the
         // corner row, the three others are 64-bit additions of the uniform row / slice pitches
         const uint32_t vsz = VOXEL == VV_VOXEL_F32 ? 4u : 1u;
@@ -337,6 +343,15 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
             const char *zr = (const char *)V.data + (uint64_t)iz * V.slice_bytes;
             load_rows<VOXEL>(zr, V.row_bytes, V.slice_bytes, ix, __umul24(iy, V.row_bytes), C);
         }
+    } else if constexpr (LAYOUT == LAYOUT_ZFAST) {
+        // z-fastest copy (f32): four z-pairs -- (x, y), (x, y+1), (x+1, y), (x+1, y+1), each (z, z+1) -- are the same eight corners; they are
+        // handed on under the names the x-pair loads give them, so everything after the fetch is the linear layout's code
+        const char *xb = (const char *)V.zfast + (uint64_t)ix * V.zf_slice_bytes + (__umul24(iy, V.zf_row_bytes) + iz * 4u);
+        const char *xb1 = xb + V.zf_slice_bytes;
+        const float2u p00 = *(const float2u *)xb, p01 = *(const float2u *)(xb + V.zf_row_bytes);        // (c000, c001), (c010, c011)
+        const float2u p10 = *(const float2u *)xb1, p11 = *(const float2u *)(xb1 + V.zf_row_bytes);      // (c100, c101), (c110, c111)
+        C.a.x = p00.x; C.a.y = p10.x; C.b.x = p01.x; C.b.y = p11.x;          // a = (c000, c100), b = (c010, c110)
+        C.c.x = p00.y; C.c.y = p10.y; C.d.x = p01.y; C.d.y = p11.y;          // c = (c001, c101), d = (c011, c111)
     } else {
         // bricked copy: the rows y / y+1 and the slices z / z+1 of a sample sit in the same brick
         // unless (y & 3) == 3 resp. (z & 3) == 3; the x pair always does (halo voxel)

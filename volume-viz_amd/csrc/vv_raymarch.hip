@@ -32,6 +32,9 @@ constexpr int kLayout = vv::LAYOUT_BRICKED;
 #elif defined(VV_BRICKED)
 #define VV_BIG_NS brick
 constexpr int kLayout = vv::LAYOUT_BRICKED;
+#elif defined(VV_ZFAST)
+#define VV_BIG_NS zfast
+constexpr int kLayout = vv::LAYOUT_ZFAST;
 #elif defined(VV_BIG_VOLUME)
 #define VV_BIG_NS big
 constexpr int kLayout = vv::LAYOUT_LINEAR_BIG;
@@ -597,7 +600,7 @@ template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 // Registers: on the linear layout up to 4 GiB the kernel is compiled for 5 waves per SIMD (83-85 VGPRs: the volumes that
 // live in the caches want 5 blocks per CU; C1 0.196 -> 0.174 ms, 256^3 1.36 -> 1.28); the variants for volumes beyond
 // 4 GiB and for the bricked copy run 2-3 blocks per CU and are 2-7 % faster with the 106 VGPRs the compiler takes by itself.
-#if defined(VV_BIG_VOLUME) || defined(VV_BRICKED)
+#if defined(VV_BIG_VOLUME) || defined(VV_BRICKED) || defined(VV_ZFAST)
 #define VV_PHONG_OCC
 #else
 #define VV_PHONG_OCC __attribute__((amdgpu_waves_per_eu(5)))
@@ -959,6 +962,8 @@ void launch_raymarch_zpair(const MarchArgs &a, hipStream_t s) { zpair::launch_ra
 void launch_raymarch_bricked_cached(const MarchArgs &a, hipStream_t s) { brickc::launch_raymarch_impl(a, s); }
 #elif defined(VV_BRICKED)
 void launch_raymarch_bricked(const MarchArgs &a, hipStream_t s) { brick::launch_raymarch_impl(a, s); }
+#elif defined(VV_ZFAST)
+void launch_raymarch_zfast(const MarchArgs &a, hipStream_t s) { zfast::launch_raymarch_impl(a, s); }
 #elif defined(VV_BIG_VOLUME)
 void launch_raymarch_big(const MarchArgs &a, hipStream_t s) { big::launch_raymarch_impl(a, s); }
 #else
