@@ -884,8 +884,8 @@ def test_zpair_copy_is_bit_identical(ctx, seed, monkeypatch):
 @pytest.mark.parametrize("seed", range(2, 62, 3))
 def test_zfast_copy_is_bit_identical(ctx, seed, monkeypatch):
     """The z-fastest copy of an f32 volume (rows along z: the front view's kernel for side views; VV_ZFAST=1 forces it for every unshaded
-    frame whose screen x does not run along the volume's x) on the random sweep's cases: any view, ragged sizes, cutting planes, shards.
-    u8 volumes and shaded frames keep their layouts."""
+    frame whose screen x does not run along the volume's x) on the random sweep's cases: any view, ragged sizes, cutting planes, shards,
+    Phong.  u8 volumes keep their layouts."""
     monkeypatch.setenv("VV_ZFAST", "1")
     vol, tf, W, H, cam, sp, phong, o = _random_case(seed)
     if seed % 2 == 0 and vol.dtype != np.float32:
@@ -898,7 +898,7 @@ def test_zfast_copy_is_bit_identical(ctx, seed, monkeypatch):
     want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
     assert_frames_close(got, want, f"zfast seed {seed}: {vol.shape} {vol.dtype} phong={phong} layout {lay['layout']}")
     assert n_got == n
-    if vol.dtype != np.float32 or phong:
+    if vol.dtype != np.float32:
         assert lay["layout"] != 4
 
 
@@ -915,14 +915,15 @@ def test_zfast_side_views(ctx, monkeypatch):
         for cam in (vv.Camera(origin=(4.0, 0.0, 0.0)), vv.Camera(origin=(-3.5, 0.3, 0.2)), vv.Camera(origin=(3.8, -0.4, 0.5))):
             for ert, filt in ((vv.ERT_REFERENCE, vv.FILTER_TEX8), (vv.ERT_TRUE, vv.FILTER_EXACT)):
                 o = dict(step=1 / 40, ert_mode=ert, ert_threshold=0.9, filter=filt)
-                got = ctx.render(97, 61, cam, options=vv.make_options(count_samples=True, **o))
-                n_got = ctx.last_sample_count()
-                took += ctx.last_launch()["layout"] == 4
-                want, n = O.render(vol, tf, 97, 61, cam, options=vv.make_options(**o))
-                assert_frames_close(got, want, f"zfast side view {dims} {cam.origin} ert{ert} filt{filt}")
-                assert n_got == n
+                for phong in (False, True):
+                    got = ctx.render(97, 61, cam, phong=phong, options=vv.make_options(count_samples=True, **o))
+                    n_got = ctx.last_sample_count()
+                    took += ctx.last_launch()["layout"] == 4
+                    want, n = O.render(vol, tf, 97, 61, cam, phong=phong, options=vv.make_options(**o))
+                    assert_frames_close(got, want, f"zfast side view {dims} {cam.origin} ert{ert} filt{filt} phong={phong}")
+                    assert n_got == n
         assert ctx.device_bytes()[2] > 0
-    assert took >= 36, took
+    assert took >= 72, took
     ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
     assert ctx.device_bytes()[2] == 0
 

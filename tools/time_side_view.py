@@ -10,12 +10,13 @@ ctx = vv.Context(0); dev = torch.device("cuda", 0); stream = torch.cuda.current_
 v8 = torch.empty(n ** 3, dtype=torch.uint8, device=dev); ctx.generate_noise_device(v8.data_ptr(), n, n, n, 0x9E3779B9, stream)
 v32 = torch.empty(n ** 3, dtype=torch.float32, device=dev); ctx.promote_device(v8.data_ptr(), v32.data_ptr(), n ** 3, stream)
 frame = torch.zeros(H * W, dtype=torch.int32, device=dev)
+PHONG = len(sys.argv) > 1 and sys.argv[1] == "phong"
 def timed(cam, frames=20):
     o = vv.make_options(step=1 / steps)
-    for _ in range(30): ctx.render_device(W, H, cam, frame.data_ptr(), options=o, stream=stream)
+    for _ in range(30): ctx.render_device(W, H, cam, frame.data_ptr(), options=o, stream=stream, phong=PHONG)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(frames): ctx.render_device(W, H, cam, frame.data_ptr(), options=o, stream=stream)
+    for _ in range(frames): ctx.render_device(W, H, cam, frame.data_ptr(), options=o, stream=stream, phong=PHONG)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / frames
 cams = {"front (0, 0, -4)": vv.Camera(), "side (4, 0, 0)": vv.Camera(origin=(4.0, 0.0, 0.0)), "side (-4, 0, 0)": vv.Camera(origin=(-4.0, 0.0, 0.0)),

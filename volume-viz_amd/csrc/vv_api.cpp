@@ -875,9 +875,9 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     const vv_knobs &K = c->knobs;
     // z-fastest copy (speed only): when the screen x direction maps onto the volume's z axis (side views) the same 32 x 2 tile reads whole
     // lines of a copy whose rows run along z -- the front view's kernel and time instead of the bricked copy's (1.5 -> 1.0 ms on C3).  f32
-    // volumes beyond the caches, unshaded frames, built on first use if HBM has room (one more copy of the volume).  VV_ZFAST=0/1 overrides.
+    // volumes beyond the caches, both kernels, built on first use if HBM has room (one more copy of the volume).  VV_ZFAST=0/1 overrides.
     bool use_zfast = false;
-    if (have_basis && A.strips.tile_log2w == 3 && c->vtype == VV_VOXEL_F32 && !shading->phongShading) {
+    if (have_basis && A.strips.tile_log2w == 3 && c->vtype == VV_VOXEL_F32) {
         const float ax = fabsf(P.side[0]) , ay = fabsf(P.side[1]), az = fabsf(P.side[2]);
         use_zfast = az >= 0.97f * sqrtf(ax * ax + ay * ay + az * az) && c->vol_bytes > (1ull << 30);
         if (K.zfast >= 0) use_zfast = K.zfast != 0;

@@ -15,10 +15,11 @@
 #include "vv_device.h"
 #include "vv_kernels.h"
 
-// This file is compiled five times: as is (linear volume up to 4 GiB), through vv_raymarch_big.hip
+// This file is compiled six times: as is (linear volume up to 4 GiB), through vv_raymarch_big.hip
 // with VV_BIG_VOLUME (linear, 64-bit slice addressing), through vv_raymarch_brick.hip with
 // VV_BRICKED (volume sampled from the bricked copy), through vv_raymarch_brick_cached.hip (the same for volumes
-// that live in the caches) and through vv_raymarch_zpair.hip with VV_ZPAIR (volume sampled from the z-pair copy),
+// that live in the caches), through vv_raymarch_zpair.hip with VV_ZPAIR (volume sampled from the z-pair copy) and through
+// vv_raymarch_zfast.hip with VV_ZFAST (f32 volume sampled from the z-fastest copy: side views),
 // so that each path pays only for itself.  The builds for cache-resident volumes (this file as is, z-pair, brick_cached)
 // are compiled with -fno-slp-vectorize: the packed-f32 code the SLP vectoriser makes of the lerps costs a v_mov per
 // operand pair, which VALU-bound frames pay for (C2 -6 %, C1 -4 %, 512^3 -4 %, C2 rotated -6.5 %, Phong -3 ... -6 %),
