@@ -924,8 +924,12 @@ def test_zfast_side_views(ctx, monkeypatch):
                     assert n_got == n
         assert ctx.device_bytes()[2] > 0
     assert took >= 72, took
+    # built up front on request (f32 only: a u8 volume reports the layout as not built)
+    vol = rng.integers(0, 256, size=(9, 10, 12), dtype=np.uint8).astype(np.float32) / np.float32(255)
+    ctx.load_volume(vol, tf)
+    assert ctx.prepare_layouts(vv.LAYOUT_ZFAST) == vv.LAYOUT_ZFAST and ctx.device_bytes()[2] == (12 + 1) * 10 * 9 * 4 + 9 * 4 + 16
     ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
-    assert ctx.device_bytes()[2] == 0
+    assert ctx.device_bytes()[2] == 0 and ctx.prepare_layouts(vv.LAYOUT_ZFAST) == 0
 
 
 def test_zpair_default_policy_and_edges(ctx, monkeypatch):

@@ -301,11 +301,12 @@ int vv_prepare_layouts(vv_context *c, int which, void *stream)
 {
     if (!c) return fail(nullptr, VV_ERR_INVALID, "vv_prepare_layouts: NULL context");
     if (!c->d_vol) return fail(c, VV_ERR_NO_VOLUME, "vv_prepare_layouts: no volume loaded");
-    if (which & ~(VV_LAYOUT_BRICKED | VV_LAYOUT_ZPAIR)) return fail(c, VV_ERR_INVALID, "vv_prepare_layouts: unknown layout bit");
+    if (which & ~(VV_LAYOUT_BRICKED | VV_LAYOUT_ZPAIR | VV_LAYOUT_ZFAST)) return fail(c, VV_ERR_INVALID, "vv_prepare_layouts: unknown layout bit");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = pick_stream(c, stream);
     int built = 0;
     if (which & VV_LAYOUT_BRICKED) c->bricks_failed = false;       // an explicit request retries after an earlier shortage of HBM
+    if (which & VV_LAYOUT_ZFAST) c->zfast_failed = false;
     if ((which & VV_LAYOUT_BRICKED) && ensure_bricks(c, st)) built |= VV_LAYOUT_BRICKED;
     if ((which & VV_LAYOUT_ZPAIR) && ensure_zpair(c, st)) built |= VV_LAYOUT_ZPAIR;
     if ((which & VV_LAYOUT_ZFAST) && ensure_zfast(c, st)) built |= VV_LAYOUT_ZFAST;

@@ -27,7 +27,7 @@ SLICE_NONE, SLICE_PLANE, SLICE_PLANE_CUT = -1, 0, 1
 # params.h:46
 HORIZONTAL, SAGITTAL, CORONAL, FREE_FORM = 0, 1, 2, 4
 VOXEL_U8, VOXEL_F32 = 0, 1
-LAYOUT_BRICKED, LAYOUT_ZPAIR = 1, 2
+LAYOUT_BRICKED, LAYOUT_ZPAIR, LAYOUT_ZFAST = 1, 2, 4
 FILTER_TEX8, FILTER_EXACT = 0, 1
 ERT_REFERENCE, ERT_TRUE = 0, 1
 RAYS_IMAGES, RAYS_ANALYTIC = 0, 1
@@ -440,7 +440,7 @@ class Context:
         return rc
 
     def device_bytes(self):
-        """vv_device_bytes: [linear volume, bricked copy, z-pair copy, tables + scratch]."""
+        """vv_device_bytes: [linear volume, bricked copy, z-pair + z-fastest copies, tables + scratch]."""
         out = np.zeros(4, np.uint64)
         self._chk(self.lib.vv_device_bytes(self.h, out.ctypes.data))
         return [int(v) for v in out]
