@@ -883,13 +883,11 @@ def test_zpair_copy_is_bit_identical(ctx, seed, monkeypatch):
 
 @pytest.mark.parametrize("seed", range(2, 62, 3))
 def test_zfast_copy_is_bit_identical(ctx, seed, monkeypatch):
-    """The z-fastest copy of an f32 volume (rows along z: the front view's kernel for side views; VV_ZFAST=1 forces it for every unshaded
-    frame whose screen x does not run along the volume's x) on the random sweep's cases: any view, ragged sizes, cutting planes, shards,
-    Phong.  u8 volumes keep their layouts."""
+    """The z-fastest copy of the volume (rows along z: the front view's kernel for side views; VV_ZFAST=1 forces it for every frame whose
+    screen x does not run along the volume's x) on the random sweep's cases: any view, both voxel types, ragged sizes, cutting planes,
+    shards, Phong."""
     monkeypatch.setenv("VV_ZFAST", "1")
     vol, tf, W, H, cam, sp, phong, o = _random_case(seed)
-    if seed % 2 == 0 and vol.dtype != np.float32:
-        vol = vol.astype(np.float32) / np.float32(255)
     ctx.load_volume(vol, tf)
     opts = vv.make_options(**o)
     got = ctx.render(W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
@@ -898,19 +896,20 @@ def test_zfast_copy_is_bit_identical(ctx, seed, monkeypatch):
     want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
     assert_frames_close(got, want, f"zfast seed {seed}: {vol.shape} {vol.dtype} phong={phong} layout {lay['layout']}")
     assert n_got == n
-    if vol.dtype != np.float32:
-        assert lay["layout"] != 4
+    assert lay["layout"] == 4 or lay["tile_log2w"] == 5          # (screen x along the volume's x: the linear layout or the z-pair copy)
 
 
 def test_zfast_side_views(ctx, monkeypatch):
-    """Side views (camera on the x axis, either side, tilted a little) of f32 volumes through the z-fastest copy: the policy picks it for
-    volumes beyond the caches only, so it is forced here; edge sizes; the copy is accounted for and dropped with the volume."""
+    """Side views (camera on the x axis, either side, tilted a little) through the z-fastest copy, both voxel types: the policy picks it for
+    volumes of 2 M voxels and more, so it is forced here; edge sizes; the copy is accounted for and dropped with the volume."""
     monkeypatch.setenv("VV_ZFAST", "1")
     tf = vv.transfer_preset(vv.TF_ENGINE)
     rng = np.random.default_rng(11)
     took = 0
     for k, dims in enumerate(((1, 1, 1), (3, 1, 2), (5, 4, 3), (17, 16, 15), (2, 9, 33), (64, 48, 40), (256, 7, 258))):
-        vol = (rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)).astype(np.float32) / np.float32(255)
+        vol = rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)
+        if k % 2 == 0:
+            vol = vol.astype(np.float32) / np.float32(255)
         ctx.load_volume(vol, tf)
         for cam in (vv.Camera(origin=(4.0, 0.0, 0.0)), vv.Camera(origin=(-3.5, 0.3, 0.2)), vv.Camera(origin=(3.8, -0.4, 0.5))):
             for ert, filt in ((vv.ERT_REFERENCE, vv.FILTER_TEX8), (vv.ERT_TRUE, vv.FILTER_EXACT)):
@@ -924,12 +923,32 @@ def test_zfast_side_views(ctx, monkeypatch):
                     assert n_got == n
         assert ctx.device_bytes()[2] > 0
     assert took >= 72, took
-    # built up front on request (f32 only: a u8 volume reports the layout as not built)
+    # built up front on request
     vol = rng.integers(0, 256, size=(9, 10, 12), dtype=np.uint8).astype(np.float32) / np.float32(255)
     ctx.load_volume(vol, tf)
     assert ctx.prepare_layouts(vv.LAYOUT_ZFAST) == vv.LAYOUT_ZFAST and ctx.device_bytes()[2] == (12 + 1) * 10 * 9 * 4 + 9 * 4 + 16
     ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
-    assert ctx.device_bytes()[2] == 0 and ctx.prepare_layouts(vv.LAYOUT_ZFAST) == 0
+    assert ctx.device_bytes()[2] == 0
+    assert ctx.prepare_layouts(vv.LAYOUT_ZFAST) == vv.LAYOUT_ZFAST and ctx.device_bytes()[2] == (4 + 1) * 4 * 4 + 4 + 16
+
+
+def test_zfast_default_policy(ctx, monkeypatch):
+    """Default policy: a side view of a volume of 2 M voxels or more samples the z-fastest copy (both voxel types, both kernels); the front
+    view and a view 30 degrees off the x axis do not."""
+    monkeypatch.delenv("VV_ZFAST", raising=False)
+    tf = vv.transfer_preset(vv.TF_HEAD)
+    base = O.noise_u8(130, 129, 131, 5)
+    for vol in (base, base.astype(np.float32) / np.float32(255)):
+        ctx.load_volume(vol, tf)
+        for cam, phong, lay4 in ((vv.Camera(origin=(4.0, 0.1, 0.2)), False, True), (vv.Camera(origin=(-4.0, 0.0, 0.3)), True, True),
+                                 (vv.Camera(), False, False), (vv.Camera.orbit(4.0, np.pi / 2, np.radians(30.0)), False, False)):
+            opts = vv.make_options(step=1 / 100, count_samples=True)
+            got = ctx.render(160, 100, cam, phong=phong, options=opts)
+            n_got = ctx.last_sample_count()
+            assert (ctx.last_launch()["layout"] == 4) == lay4, (vol.dtype, cam.origin, ctx.last_launch())
+            want, n = O.render(vol, tf, 160, 100, cam, phong=phong, options=opts)
+            assert_frames_close(got, want, f"zfast policy {vol.dtype} {cam.origin} phong={phong}")
+            assert n_got == n
 
 
 def test_zpair_default_policy_and_edges(ctx, monkeypatch):

@@ -644,25 +644,27 @@ static bool ensure_zpair(vv_context *c, hipStream_t st)
     return true;
 }
 
-// The z-fastest copy of an f32 volume (VolumeView::zfast): rows of nz voxels padded like the linear layout's rows (finalize_layout),
+// The z-fastest copy of the volume (VolumeView::zfast): rows of nz voxels padded like the linear layout's rows (finalize_layout),
 // ny rows per slice, nx slices + one slice, one row and 16 bytes of zeros behind them (the weight-0 corners of edge samples).
 static bool ensure_zfast(vv_context *c, hipStream_t st)
 {
     if (c->zfast_valid) return true;
-    if (c->zfast_failed || c->vtype != VV_VOXEL_F32) return false;
-    size_t row = (size_t)c->nz * 4;
+    if (c->zfast_failed) return false;
+    const size_t vsz = c->vtype == VV_VOXEL_F32 ? 4 : 1;
+    size_t row = (size_t)c->nz * vsz;
     if (row % 1024 == 0) row += 32;
+    else if (vsz == 1) row = (row + 3) & ~(size_t)3;                       // (u8 rows are read as aligned dwords)
     size_t rows = (size_t)c->ny;
-    if (row != (size_t)c->nz * 4 && (rows * row) % 4096 == 0) rows += 1;
+    if (row % 1024 == 32 && (rows * row) % 4096 == 0) rows += 1;
     const size_t slice = rows * row, bytes = slice * ((size_t)c->nx + 1) + row + 16;
     size_t free_b = 0, total_b = 0;
-    if (row >= (1u << 24) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (512ull << 20) ||
+    if (row >= (1u << 24) || slice >= (1ull << 32) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (512ull << 20) ||
         hipMalloc(&c->d_zfast, bytes) != hipSuccess) {
         (void)hipGetLastError(); c->d_zfast = nullptr; c->zfast_failed = true;
         return false;                                                     // no room: the bricked copy serves the view
     }
     if (hipMemsetAsync(c->d_zfast, 0, bytes, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(c->d_zfast); c->d_zfast = nullptr; c->zfast_failed = true; return false; }
-    launch_build_zfast((const float *)c->d_vol, (uint32_t)c->row_pitch, (uint64_t)c->slice_pitch, (float *)c->d_zfast, (uint32_t)row, (uint64_t)slice, c->nx, c->ny, c->nz, st);
+    launch_build_zfast(c->vtype, c->d_vol, (uint32_t)c->row_pitch, (uint64_t)c->slice_pitch, c->d_zfast, (uint32_t)row, (uint64_t)slice, c->nx, c->ny, c->nz, st);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {      // later frames may come on another stream
         (void)hipGetLastError(); (void)hipFree(c->d_zfast); c->d_zfast = nullptr; c->zfast_failed = true;
         return false;
@@ -875,12 +877,13 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     }
     const vv_knobs &K = c->knobs;
     // z-fastest copy (speed only): when the screen x direction maps onto the volume's z axis (side views) the same 32 x 2 tile reads whole
-    // lines of a copy whose rows run along z -- the front view's kernel and time instead of the bricked copy's (1.5 -> 1.0 ms on C3).  f32
-    // volumes beyond the caches, both kernels, built on first use if HBM has room (one more copy of the volume).  VV_ZFAST=0/1 overrides.
+    // lines of a copy whose rows run along z -- the front view's kernel instead of the bricked copy's (C3 1.33 -> 1.0 ms, C2 0.223 -> 0.186,
+    // profiles/r04_side_view.txt).  Both voxel types, both kernels, every volume the bricked copy would serve; built on first use if HBM has
+    // room (one more copy of the volume).  VV_ZFAST=0/1 overrides.
     bool use_zfast = false;
-    if (have_basis && A.strips.tile_log2w == 3 && c->vtype == VV_VOXEL_F32) {
+    if (have_basis && A.strips.tile_log2w == 3) {
         const float ax = fabsf(P.side[0]) , ay = fabsf(P.side[1]), az = fabsf(P.side[2]);
-        use_zfast = az >= 0.97f * sqrtf(ax * ax + ay * ay + az * az) && c->vol_bytes > (1ull << 30);
+        use_zfast = az >= 0.97f * sqrtf(ax * ax + ay * ay + az * az) && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
         if (K.zfast >= 0) use_zfast = K.zfast != 0;
     }
     if (use_zfast) use_zfast = ensure_zfast(c, st);

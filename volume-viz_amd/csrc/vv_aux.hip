@@ -768,31 +768,35 @@ void launch_build_zpair(int vtype, const void *linear, size_t row_pitch, size_t 
 }
 
 // ---------------------------------------------------------------------------
-// z-fastest copy of an f32 volume (VolumeView::zfast): out(x, y, z) = in(z, y, x) -- for every y a transpose of the (z, x) plane through
+// z-fastest copy of a volume (VolumeView::zfast): out(x, y, z) = in(z, y, x) -- for every y a transpose of the (z, x) plane through
 // 32 x 32 tiles in LDS (33 columns: no bank conflicts), reads and writes in whole lines
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void zfast_kernel(const float *__restrict__ in, uint32_t row_pitch, uint64_t slice_pitch, float *__restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void zfast_kernel(const T *__restrict__ in, uint32_t row_pitch, uint64_t slice_pitch, T *__restrict__ out,
                                                     uint32_t zf_row_bytes, uint64_t zf_slice_bytes, int nx, int ny, int nz)
 {
-    __shared__ float tile[32][33];
+    __shared__ T tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8 threads
     const int x0 = blockIdx.x * 32, z0 = blockIdx.y * 32, y = blockIdx.z;
     for (int r = ty; r < 32; r += 8) {
         const int z = z0 + r, x = x0 + tx;
-        tile[r][tx] = (z < nz && x < nx) ? ((const float *)((const char *)in + (uint64_t)z * slice_pitch + (uint64_t)y * row_pitch))[x] : 0.f;
+        tile[r][tx] = (z < nz && x < nx) ? ((const T *)((const char *)in + (uint64_t)z * slice_pitch + (uint64_t)y * row_pitch))[x] : T(0);
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int x = x0 + r, z = z0 + tx;
-        if (x < nx && z < nz) ((float *)((char *)out + (uint64_t)x * zf_slice_bytes + (uint64_t)y * zf_row_bytes))[z] = tile[tx][r];
+        if (x < nx && z < nz) ((T *)((char *)out + (uint64_t)x * zf_slice_bytes + (uint64_t)y * zf_row_bytes))[z] = tile[tx][r];
     }
 }
 
-void launch_build_zfast(const float *vol, uint32_t row_pitch, uint64_t slice_pitch, float *out, uint32_t zf_row_bytes, uint64_t zf_slice_bytes, int nx, int ny, int nz, hipStream_t s)
+void launch_build_zfast(int vtype, const void *vol, uint32_t row_pitch, uint64_t slice_pitch, void *out, uint32_t zf_row_bytes, uint64_t zf_slice_bytes, int nx, int ny, int nz, hipStream_t s)
 {
     // (grid.z <= 65535: volumes are at most 4096 voxels on a side for the sampler's 24-bit multiplies)
-    hipLaunchKernelGGL(zfast_kernel, dim3((unsigned)((nx + 31) / 32), (unsigned)((nz + 31) / 32), (unsigned)ny), dim3(256), 0, s,
-                       vol, row_pitch, slice_pitch, out, zf_row_bytes, zf_slice_bytes, nx, ny, nz);
+    const dim3 grid((unsigned)((nx + 31) / 32), (unsigned)((nz + 31) / 32), (unsigned)ny);
+    if (vtype == VV_VOXEL_F32)
+        hipLaunchKernelGGL(zfast_kernel<float>, grid, dim3(256), 0, s, (const float *)vol, row_pitch, slice_pitch, (float *)out, zf_row_bytes, zf_slice_bytes, nx, ny, nz);
+    else
+        hipLaunchKernelGGL(zfast_kernel<uint8_t>, grid, dim3(256), 0, s, (const uint8_t *)vol, row_pitch, slice_pitch, (uint8_t *)out, zf_row_bytes, zf_slice_bytes, nx, ny, nz);
 }
 
 // ---------------------------------------------------------------------------

@@ -56,8 +56,8 @@ struct VolumeView {
     const void *zpair;
     uint32_t zp_row_bytes;  // (nx+1) records, u8 rows rounded up to 4 bytes
     uint32_t zp_slab_bytes; // (ny+1) * zp_row_bytes
-    // Optional z-fastest copy of an f32 volume for views whose screen x runs along the volume's z axis (side views; built on first use):
-    // voxel (x, y, z) at zfast + x * zf_slice_bytes + y * zf_row_bytes + 4 z, padded like the linear layout.  The lanes of a wave tile then
+    // Optional z-fastest copy for views whose screen x runs along the volume's z axis (side views; built on first use):
+    // voxel (x, y, z) at zfast + x * zf_slice_bytes + y * zf_row_bytes + z * sizeof(voxel), padded like the linear layout.  The lanes of a wave tile then
     // read consecutive z, as they read consecutive x of the linear layout in a front view: the same kernel, the same time.
     const void *zfast;
     uint32_t zf_row_bytes;  // nz * 4 (+ padding)
@@ -332,7 +332,7 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
         // up to 4 GiB: one 32-bit byte offset per sample added to four scalar bases (saddr + voffset)
         load_rows<VOXEL>((const char *)V.data, V.row_bytes, V.slice_bytes, ix,
                          __umul24(iy, V.row_bytes) + __umul24(iz, V.slice_bytes), C);
-    } else if constexpr (LAYOUT == LAYOUT_LINEAR_BIG || (LAYOUT == LAYOUT_ZFAST && VOXEL != VV_VOXEL_F32)) {      // (the z-fastest build's u8 kernels are never launched on that copy)
+    } else if constexpr (LAYOUT == LAYOUT_LINEAR_BIG) {
         // volumes above 4 GiB (separate kernel instantiations): one 64-bit address per lane for the
         // corner row, the three others are 64-bit additions of the uniform row / slice pitches
         const uint32_t vsz = VOXEL == VV_VOXEL_F32 ? 4u : 1u;
@@ -344,14 +344,19 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
             load_rows<VOXEL>(zr, V.row_bytes, V.slice_bytes, ix, __umul24(iy, V.row_bytes), C);
         }
     } else if constexpr (LAYOUT == LAYOUT_ZFAST) {
-        // z-fastest copy (f32): four z-pairs -- (x, y), (x, y+1), (x+1, y), (x+1, y+1), each (z, z+1) -- are the same eight corners; they are
-        // handed on under the names the x-pair loads give them, so everything after the fetch is the linear layout's code
-        const char *xb = (const char *)V.zfast + (uint64_t)ix * V.zf_slice_bytes + (__umul24(iy, V.zf_row_bytes) + iz * 4u);
-        const char *xb1 = xb + V.zf_slice_bytes;
-        const float2u p00 = *(const float2u *)xb, p01 = *(const float2u *)(xb + V.zf_row_bytes);        // (c000, c001), (c010, c011)
-        const float2u p10 = *(const float2u *)xb1, p11 = *(const float2u *)(xb1 + V.zf_row_bytes);      // (c100, c101), (c110, c111)
-        C.a.x = p00.x; C.a.y = p10.x; C.b.x = p01.x; C.b.y = p11.x;          // a = (c000, c100), b = (c010, c110)
-        C.c.x = p00.y; C.c.y = p10.y; C.d.x = p01.y; C.d.y = p11.y;          // c = (c001, c101), d = (c011, c111)
+        // z-fastest copy: the loads of the linear layout with z in the role of x -- rows (x, y), (x, y+1), (x+1, y), (x+1, y+1), each holding
+        // the voxels z and z+1 (f32: one pair; u8: two aligned dwords, shifted in finish_corners) -- are the same eight corners.  f32 corners
+        // are handed on under the names the x-pair loads give them; u8 corners are renamed where the bytes are taken apart (VV_ZFAST there).
+        const char *xb = (const char *)V.zfast + (uint64_t)ix * V.zf_slice_bytes;
+        if constexpr (VOXEL == VV_VOXEL_F32) {
+            Corners<VOXEL> T;
+            load_rows<VOXEL>(xb + (__umul24(iy, V.zf_row_bytes) + iz * 4u), V.zf_row_bytes, (uint32_t)V.zf_slice_bytes, 0u, 0u, T);
+            // T.a = (c000, c001), T.b = (c010, c011), T.c = (c100, c101), T.d = (c110, c111)
+            C.a.x = T.a.x; C.a.y = T.c.x; C.b.x = T.b.x; C.b.y = T.d.x;      // a = (c000, c100), b = (c010, c110)
+            C.c.x = T.a.y; C.c.y = T.c.y; C.d.x = T.b.y; C.d.y = T.d.y;      // c = (c001, c101), d = (c011, c111)
+        } else {
+            load_rows<VOXEL>(xb, V.zf_row_bytes, (uint32_t)V.zf_slice_bytes, iz, __umul24(iy, V.zf_row_bytes), C);
+        }
     } else {
         // bricked copy: the rows y / y+1 and the slices z / z+1 of a sample sit in the same brick
         // unless (y & 3) == 3 resp. (z & 3) == 3; the x pair always does (halo voxel)
@@ -465,8 +470,13 @@ __device__ __forceinline__ float finish_corners(const Corners<VOXEL> &C)
         // v_alignbyte shifts each dword pair so that byte 0 is voxel x
         const uint32_t a = __builtin_amdgcn_alignbyte(C.a1, C.a0, C.sh), b = __builtin_amdgcn_alignbyte(C.b1, C.b0, C.sh);
         const uint32_t c = __builtin_amdgcn_alignbyte(C.c1, C.c0, C.sh), d = __builtin_amdgcn_alignbyte(C.d1, C.d0, C.sh);
+#ifdef VV_ZFAST      // (the z-fastest build: byte 0 / 1 are voxels z / z+1 of the rows (x, y), (x, y+1), (x+1, y), (x+1, y+1))
+        c000 = (float)(a & 0xffu); c001 = (float)((a >> 8) & 0xffu); c010 = (float)(b & 0xffu); c011 = (float)((b >> 8) & 0xffu);
+        c100 = (float)(c & 0xffu); c101 = (float)((c >> 8) & 0xffu); c110 = (float)(d & 0xffu); c111 = (float)((d >> 8) & 0xffu);
+#else
         c000 = (float)(a & 0xffu); c100 = (float)((a >> 8) & 0xffu); c010 = (float)(b & 0xffu); c110 = (float)((b >> 8) & 0xffu);
         c001 = (float)(c & 0xffu); c101 = (float)((c >> 8) & 0xffu); c011 = (float)(d & 0xffu); c111 = (float)((d >> 8) & 0xffu);
+#endif
     }
     float c00 = __builtin_fmaf(C.wx, c100 - c000, c000);
     float c10 = __builtin_fmaf(C.wx, c110 - c010, c010);

@@ -65,8 +65,8 @@ void launch_raymarch_big(const MarchArgs &a, hipStream_t s);      // same kernel
 void launch_raymarch_bricked(const MarchArgs &a, hipStream_t s);  // same kernels on VolumeView::bricks
 void launch_raymarch_bricked_cached(const MarchArgs &a, hipStream_t s);  // ... the build for volumes up to 1 GiB
 void launch_raymarch_zpair(const MarchArgs &a, hipStream_t s);    // same kernels on VolumeView::zpair
-void launch_raymarch_zfast(const MarchArgs &a, hipStream_t s);    // same kernels on VolumeView::zfast (f32)
-void launch_build_zfast(const float *vol, uint32_t row_pitch, uint64_t slice_pitch, float *out, uint32_t zf_row_bytes, uint64_t zf_slice_bytes, int nx, int ny, int nz, hipStream_t s);
+void launch_raymarch_zfast(const MarchArgs &a, hipStream_t s);    // same kernels on VolumeView::zfast
+void launch_build_zfast(int vtype, const void *vol, uint32_t row_pitch, uint64_t slice_pitch, void *out, uint32_t zf_row_bytes, uint64_t zf_slice_bytes, int nx, int ny, int nz, hipStream_t s);
 size_t zpair_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *row_bytes, uint32_t *slab_bytes);
 void launch_build_zpair(int vtype, const void *linear, size_t row_pitch, size_t slice_pitch, void *zpair, int nx, int ny, int nz, hipStream_t s);
 void launch_repitch(const void *dense, void *pitched, size_t row_bytes /* multiple of 16 */, size_t ny, size_t nz,
