@@ -896,7 +896,7 @@ def test_zfast_copy_is_bit_identical(ctx, seed, monkeypatch):
     want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=phong, options=opts, fill=0x3C)
     assert_frames_close(got, want, f"zfast seed {seed}: {vol.shape} {vol.dtype} phong={phong} layout {lay['layout']}")
     assert n_got == n
-    assert lay["layout"] == 4 or lay["tile_log2w"] == 5          # (screen x along the volume's x: the linear layout or the z-pair copy)
+    assert lay["layout"] in (4, 5) or lay["tile_log2w"] == 5     # (5: the x-pair copy; tile 5 without either: screen x along the volume's x)
 
 
 def test_zfast_side_views(ctx, monkeypatch):
@@ -917,7 +917,7 @@ def test_zfast_side_views(ctx, monkeypatch):
                 for phong in (False, True):
                     got = ctx.render(97, 61, cam, phong=phong, options=vv.make_options(count_samples=True, **o))
                     n_got = ctx.last_sample_count()
-                    took += ctx.last_launch()["layout"] == 4
+                    took += ctx.last_launch()["layout"] in (4, 5)
                     want, n = O.render(vol, tf, 97, 61, cam, phong=phong, options=vv.make_options(**o))
                     assert_frames_close(got, want, f"zfast side view {dims} {cam.origin} ert{ert} filt{filt} phong={phong}")
                     assert n_got == n
@@ -933,8 +933,8 @@ def test_zfast_side_views(ctx, monkeypatch):
 
 
 def test_zfast_default_policy(ctx, monkeypatch):
-    """Default policy: a side view of a volume of 2 M voxels or more samples the z-fastest copy (both voxel types, both kernels); the front
-    view and a view 30 degrees off the x axis do not."""
+    """Default policy: a side view of a volume of 2 M voxels or more samples the z-fastest copy (both voxel types, both kernels) or, unshaded
+    and under the z-pair copy's conditions, the x-pair copy; the front view and a view 30 degrees off the x axis do not."""
     monkeypatch.delenv("VV_ZFAST", raising=False)
     tf = vv.transfer_preset(vv.TF_HEAD)
     base = O.noise_u8(130, 129, 131, 5)
@@ -945,7 +945,9 @@ def test_zfast_default_policy(ctx, monkeypatch):
             opts = vv.make_options(step=1 / 100, count_samples=True)
             got = ctx.render(160, 100, cam, phong=phong, options=opts)
             n_got = ctx.last_sample_count()
-            assert (ctx.last_launch()["layout"] == 4) == lay4, (vol.dtype, cam.origin, ctx.last_launch())
+            assert (ctx.last_launch()["layout"] in (4, 5)) == lay4, (vol.dtype, cam.origin, ctx.last_launch())
+            if lay4:
+                assert ctx.last_launch()["layout"] == (4 if phong else 5)          # unshaded frames of small / u8 volumes: the x-pair copy
             want, n = O.render(vol, tf, 160, 100, cam, phong=phong, options=opts)
             assert_frames_close(got, want, f"zfast policy {vol.dtype} {cam.origin} phong={phong}")
             assert n_got == n

@@ -51,7 +51,8 @@ struct vv_context {
     void *d_bricks = nullptr; bool bricks_valid = false, bricks_failed = false; uint32_t b_sy = 0, b_sz64 = 0; size_t bricks_bytes = 0;
     // z-pair copy of an f32 volume for views along the memory axis (same life cycle)
     void *d_zpair = nullptr; bool zpair_valid = false; uint32_t zp_row = 0, zp_slab = 0; size_t zpair_bytes = 0;
-    void *d_zfast = nullptr; bool zfast_valid = false, zfast_failed = false; uint32_t zf_row = 0; uint64_t zf_slice = 0; size_t zfast_bytes = 0;   // z-fastest copy (f32, side views)
+    void *d_zfast = nullptr; bool zfast_valid = false, zfast_failed = false; uint32_t zf_row = 0; uint64_t zf_slice = 0; size_t zfast_bytes = 0;   // z-fastest copy (side views)
+    void *d_xpair = nullptr; bool xpair_valid = false, xpair_failed = false; uint32_t xp_row = 0, xp_slab = 0; size_t xpair_bytes = 0;           // x-pair copy (side views of small / u8 volumes)
     // transfer function
     float4 *d_tf = nullptr; bool tf_gray = false; bool have_tf = false;
     bool tf_alpha_unit = false;          // every opacity of the table lies in [0, 1]: accumulated opacity never decreases
@@ -105,6 +106,8 @@ static void drop_bricks(vv_context *c)
     c->d_zpair = nullptr; c->zpair_valid = false; c->zpair_bytes = 0;
     if (c->d_zfast) (void)hipFree(c->d_zfast);
     c->d_zfast = nullptr; c->zfast_valid = false; c->zfast_failed = false; c->zfast_bytes = 0;
+    if (c->d_xpair) (void)hipFree(c->d_xpair);
+    c->d_xpair = nullptr; c->xpair_valid = false; c->xpair_failed = false; c->xpair_bytes = 0;
 }
 
 static int ensure(vv_context *c, void **p, size_t *cap, size_t need)
@@ -170,6 +173,7 @@ static bool estimate_view_from_images(const uint8_t *front, const uint8_t *back,
 static bool ensure_bricks(vv_context *c, hipStream_t st);
 static bool ensure_zpair(vv_context *c, hipStream_t st);
 static bool ensure_zfast(vv_context *c, hipStream_t st);
+static bool ensure_xpair(vv_context *c, hipStream_t st);
 
 extern "C" {
 
@@ -384,7 +388,7 @@ int vv_device_bytes(const vv_context *c, unsigned long long out[4])
     if (!c || !out) return VV_ERR_INVALID;
     out[0] = c->d_vol ? c->alloc_bytes : 0;
     out[1] = c->bricks_valid ? c->bricks_bytes : 0;
-    out[2] = (c->zpair_valid ? c->zpair_bytes : 0) + (c->zfast_valid ? c->zfast_bytes : 0);
+    out[2] = (c->zpair_valid ? c->zpair_bytes : 0) + (c->zfast_valid ? c->zfast_bytes : 0) + (c->xpair_valid ? c->xpair_bytes : 0);
     out[3] = c->rad_cap + c->frame_cap + c->img_cap + c->slice_cap + 4096 + 8 * sizeof(unsigned long long);
     return VV_OK;
 }
@@ -670,6 +674,30 @@ static bool ensure_zfast(vv_context *c, hipStream_t st)
         return false;
     }
     c->zf_row = (uint32_t)row; c->zf_slice = (uint64_t)slice; c->zfast_bytes = bytes; c->zfast_valid = true;
+    return true;
+}
+
+// The x-pair copy (the z-pair copy with x and z exchanged; built from the z-fastest copy): the limits of ensure_zpair with the roles swapped.
+static bool ensure_xpair(vv_context *c, hipStream_t st)
+{
+    if (c->xpair_valid) return true;
+    if (c->xpair_failed || !ensure_zfast(c, st)) return false;
+    uint32_t rb = 0, sb = 0;
+    const size_t xb = zpair_copy_bytes(c->vtype, c->nz, c->ny, c->nx, &rb, &sb);
+    size_t free_b = 0, total_b = 0;
+    if ((size_t)(c->ny + 1) * ((size_t)c->nz + 1) * 8 >= (1ull << 32) || ((size_t)c->nz + 1) * 8 >= (1u << 24) ||
+        (c->vtype == VV_VOXEL_U8 && xb >= (1ull << 32)) ||                // u8 sampler: 32-bit offsets
+        hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < xb + (512ull << 20) ||
+        hipMalloc(&c->d_xpair, xb + 32) != hipSuccess) {
+        (void)hipGetLastError(); c->d_xpair = nullptr; c->xpair_failed = true;
+        return false;
+    }
+    launch_build_xpair(c->vtype, c->d_zfast, c->zf_row, c->zf_slice, c->d_xpair, c->nx, c->ny, c->nz, st);
+    if (hipMemsetAsync((char *)c->d_xpair + xb, 0, 32, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipFree(c->d_xpair); c->d_xpair = nullptr; c->xpair_failed = true;
+        return false;
+    }
+    c->xp_row = rb; c->xp_slab = sb; c->xpair_bytes = xb; c->xpair_valid = true;
     return true;
 }
 
@@ -985,6 +1013,13 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (use_zfast) use_zpair = false;
     if (use_zpair) use_zpair = ensure_zpair(c, st);
     if (use_zpair) { A.V.zpair = c->d_zpair; A.V.zp_row_bytes = c->zp_row; A.V.zp_slab_bytes = c->zp_slab; }
+    // x-pair copy (speed only): the same two-gather form for side views -- the z-pair copy with x and z exchanged, handed to the kernel in the
+    // z-pair fields of the view -- under the z-pair copy's conditions (unshaded, u8 or f32 up to 512 MiB).  Follows VV_ZPAIR=0.
+    A.xpair = false;
+    if (use_zfast && !shading->phongShading && K.zpair != 0 && (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20)) && ensure_xpair(c, st)) {
+        A.xpair = true;
+        A.V.zpair = c->d_xpair; A.V.zp_row_bytes = c->xp_row; A.V.zp_slab_bytes = c->xp_slab;
+    }
     // Phong kernel: 14.3 KB of LDS per block + this reserve.  Measured (tools/ab_phong.sh): volumes up to
     // 1 GiB like 5 blocks per CU (C2 0.54 -> 0.47 ms against no cap, u8 1024^3 1.88 -> 1.78), the 4 GiB
     // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)
@@ -1019,7 +1054,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), st));
     c->counter_valid = A.instr; c->sweep_err_valid = false;
     {
-        const int layout = A.V.zfast ? 4 : (A.V.bricks ? 2 : (A.V.zpair ? 3 : ((A.V.big || (A.phong && beyond_caches)) ? 1 : 0)));
+        const int layout = A.xpair ? 5 : A.V.zfast ? 4 : (A.V.bricks ? 2 : (A.V.zpair ? 3 : ((A.V.big || (A.phong && beyond_caches)) ? 1 : 0)));
         const int v[8] = {A.strips.tile_log2w, A.strips.blk_log2w, A.unroll, A.phong ? A.lds_reserve_phong : A.lds_reserve, layout, have_basis ? 1 : 0,
                           (int)fminf(density * 1000.f, 2e9f), A.phong ? 1 : 0};
         memcpy(c->last_launch, v, sizeof v);
@@ -1029,7 +1064,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (A.phong) {
         // (linear volumes beyond the caches take the 64-bit-addressing build even below 4 GiB: the other one is compiled for 5 waves per SIMD, which only
         //  cache-resident volumes want -- 1000^3 f32: 1.884 -> 1.817 ms, tools/ab_env.sh VV_FORCE_BIG=1)
-        if (A.V.zfast) launch_raymarch_zfast(A, st); else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); } else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big || beyond_caches) launch_raymarch_big(A, st); else launch_raymarch(A, st);
+        if (A.xpair) launch_raymarch_xpair(A, st); else if (A.V.zfast) launch_raymarch_zfast(A, st); else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); } else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big || beyond_caches) launch_raymarch_big(A, st); else launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
         bool sweep = false;
@@ -1057,6 +1092,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         }
 #endif
         if (sweep) { }
+        else if (A.xpair) launch_raymarch_xpair(A, st);
         else if (A.V.zfast) launch_raymarch_zfast(A, st);
         else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); }
         else if (A.V.zpair) launch_raymarch_zpair(A, st);

@@ -799,6 +799,39 @@ void launch_build_zfast(int vtype, const void *vol, uint32_t row_pitch, uint64_t
         hipLaunchKernelGGL(zfast_kernel<uint8_t>, grid, dim3(256), 0, s, (const uint8_t *)vol, row_pitch, slice_pitch, (uint8_t *)out, zf_row_bytes, zf_slice_bytes, nx, ny, nz);
 }
 
+// x-pair copy (the z-pair copy with x and z exchanged), built from the z-fastest copy so that both reads run along z:
+// record (z, y, x) = { v(x, y, z), v(x+1, y, z) }, rows of nz + 1 records, slabs of ny + 1 rows, nx slabs; indices beyond the volume clamp
+template <typename T, typename T2>
+__global__ __launch_bounds__(256) void xpair_kernel(const T *__restrict__ zf, uint32_t zf_row_bytes, uint64_t zf_slice_bytes, T2 *__restrict__ out,
+                                                    int nx, int ny, int nz, size_t row_recs, size_t total)
+{
+    const size_t ry = (size_t)ny + 1;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int z = min((int)(t % row_recs), nz - 1);
+        const size_t row = t / row_recs;
+        const int y = min((int)(row % ry), ny - 1), x = (int)(row / ry);
+        const char *rowp = (const char *)zf + (size_t)y * zf_row_bytes;
+        T2 r;
+        r.x = ((const T *)(rowp + (size_t)x * zf_slice_bytes))[z];
+        r.y = ((const T *)(rowp + (size_t)min(x + 1, nx - 1) * zf_slice_bytes))[z];
+        out[t] = r;
+    }
+}
+
+void launch_build_xpair(int vtype, const void *zfast, uint32_t zf_row_bytes, uint64_t zf_slice_bytes, void *xpair, int nx, int ny, int nz, hipStream_t s)
+{
+    uint32_t rb = 0, sb = 0;
+    zpair_copy_bytes(vtype, nz, ny, nx, &rb, &sb);                         // (the z-pair copy's geometry with x and z exchanged)
+    const size_t row_recs = rb / (vtype == VV_VOXEL_F32 ? 8 : 2);
+    const size_t total = row_recs * ((size_t)ny + 1) * (size_t)nx;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (vtype == VV_VOXEL_F32)
+        hipLaunchKernelGGL((xpair_kernel<float, float2>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)zfast, zf_row_bytes, zf_slice_bytes, (float2 *)xpair, nx, ny, nz, row_recs, total);
+    else
+        hipLaunchKernelGGL((xpair_kernel<uint8_t, uchar2>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)zfast, zf_row_bytes, zf_slice_bytes, (uchar2 *)xpair, nx, ny, nz, row_recs, total);
+}
+
 // ---------------------------------------------------------------------------
 // synthetic noise volume V2 (measurement input, not from the reference)
 // ---------------------------------------------------------------------------

@@ -409,12 +409,23 @@ __device__ __forceinline__ void fetch_corners_zpair(const VolumeView &V, float p
     C.wx = axis_coord<TEX8>(px, (float)V.nx, (float)(V.nx - 1), ix);
     C.wy = axis_coord<TEX8>(py, (float)V.ny, (float)(V.ny - 1), iy);
     C.wz = axis_coord<TEX8>(pz, (float)V.nz, (float)(V.nz - 1), iz);
+#ifdef VV_XPAIR
+    // x-pair copy (side views): the z-pair copy with x and z in each other's roles -- records {v(x), v(x+1)}, z fastest, slabs along x --
+    // read through the same fields of the view; the two z-neighbouring records of a row are the corners (x..x+1, y, z..z+1)
+    const char *zb = (const char *)V.zpair + (uint64_t)ix * V.zp_slab_bytes;
+    const uint32_t off = __umul24(iy, V.zp_row_bytes) + (iz << 3);
+    const float4u r0 = *(const float4u *)(zb + off);                         // (x..x+1, y, z), (x..x+1, y, z+1)
+    const float4u r1 = *(const float4u *)(zb + off + V.zp_row_bytes);        // the same for y+1
+    C.c000 = r0.x; C.c100 = r0.y; C.c001 = r0.z; C.c101 = r0.w;
+    C.c010 = r1.x; C.c110 = r1.y; C.c011 = r1.z; C.c111 = r1.w;
+#else
     const char *zb = (const char *)V.zpair + (uint64_t)iz * V.zp_slab_bytes;      // the copy of a 1024^3 volume is 8.6 GB
     const uint32_t off = __umul24(iy, V.zp_row_bytes) + (ix << 3);
     const float4u r0 = *(const float4u *)(zb + off);                         // (x, y, z..z+1), (x+1, y, z..z+1)
     const float4u r1 = *(const float4u *)(zb + off + V.zp_row_bytes);        // the same for y+1
     C.c000 = r0.x; C.c001 = r0.y; C.c100 = r0.z; C.c101 = r0.w;
     C.c010 = r1.x; C.c011 = r1.y; C.c110 = r1.z; C.c111 = r1.w;
+#endif
 }
 
 // u8 z-pair copy: records of 2 bytes, one (2-byte aligned) dword per row = (c000, c001, c100, c101).
@@ -430,15 +441,24 @@ __device__ __forceinline__ void fetch_corners_zpair(const VolumeView &V, float p
     C.wy = axis_coord<TEX8>(py, (float)V.ny, (float)(V.ny - 1), iy);
     C.wz = axis_coord<TEX8>(pz, (float)V.nz, (float)(V.nz - 1), iz);
     const char *b0 = (const char *)V.zpair, *b1 = b0 + V.zp_row_bytes;
+#ifdef VV_XPAIR
+    const uint32_t off = ix * V.zp_slab_bytes + __umul24(iy, V.zp_row_bytes) + (iz << 1);      // dword = (c000, c100, c001, c101)
+#else
     const uint32_t off = iz * V.zp_slab_bytes + __umul24(iy, V.zp_row_bytes) + (ix << 1);
+#endif
     C.r0 = *(const uint32_a2 *)(b0 + off);
     C.r1 = *(const uint32_a2 *)(b1 + off);
 }
 
 __device__ __forceinline__ float finish_corners(const CornersZ8 &C)
 {
+#ifdef VV_XPAIR
+    const float c000 = (float)(C.r0 & 0xffu), c100 = (float)((C.r0 >> 8) & 0xffu), c001 = (float)((C.r0 >> 16) & 0xffu), c101 = (float)(C.r0 >> 24);
+    const float c010 = (float)(C.r1 & 0xffu), c110 = (float)((C.r1 >> 8) & 0xffu), c011 = (float)((C.r1 >> 16) & 0xffu), c111 = (float)(C.r1 >> 24);
+#else
     const float c000 = (float)(C.r0 & 0xffu), c001 = (float)((C.r0 >> 8) & 0xffu), c100 = (float)((C.r0 >> 16) & 0xffu), c101 = (float)(C.r0 >> 24);
     const float c010 = (float)(C.r1 & 0xffu), c011 = (float)((C.r1 >> 8) & 0xffu), c110 = (float)((C.r1 >> 16) & 0xffu), c111 = (float)(C.r1 >> 24);
+#endif
     const float c00 = __builtin_fmaf(C.wx, c100 - c000, c000);
     const float c10 = __builtin_fmaf(C.wx, c110 - c010, c010);
     const float c01 = __builtin_fmaf(C.wx, c101 - c001, c001);

@@ -43,6 +43,7 @@ struct MarchArgs {
     VolumeView  V;
     int V_type;                 // vv_voxel_type
     bool tex8, gray, phong, instr;
+    bool xpair;                 // VolumeView::zpair holds the x-pair copy (side views): launch_raymarch_xpair
     int lds_reserve;            // march_kernel: dynamic LDS bytes reserved only to cap blocks per CU
     int unroll;                 // march_kernel: samples per loop trip (2 or 3; march_skew_kernel also 1)
     int lds_reserve_phong;      // march_phong_kernel: same occupancy cap (its own LDS is 14 KB)
@@ -66,6 +67,8 @@ void launch_raymarch_bricked(const MarchArgs &a, hipStream_t s);  // same kernel
 void launch_raymarch_bricked_cached(const MarchArgs &a, hipStream_t s);  // ... the build for volumes up to 1 GiB
 void launch_raymarch_zpair(const MarchArgs &a, hipStream_t s);    // same kernels on VolumeView::zpair
 void launch_raymarch_zfast(const MarchArgs &a, hipStream_t s);    // same kernels on VolumeView::zfast
+void launch_raymarch_xpair(const MarchArgs &a, hipStream_t s);    // same kernels on the x-pair copy (handed over in VolumeView::zpair)
+void launch_build_xpair(int vtype, const void *zfast, uint32_t zf_row_bytes, uint64_t zf_slice_bytes, void *xpair, int nx, int ny, int nz, hipStream_t s);
 void launch_build_zfast(int vtype, const void *vol, uint32_t row_pitch, uint64_t slice_pitch, void *out, uint32_t zf_row_bytes, uint64_t zf_slice_bytes, int nx, int ny, int nz, hipStream_t s);
 size_t zpair_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *row_bytes, uint32_t *slab_bytes);
 void launch_build_zpair(int vtype, const void *linear, size_t row_pitch, size_t slice_pitch, void *zpair, int nx, int ny, int nz, hipStream_t s);

@@ -15,16 +15,20 @@
 #include "vv_device.h"
 #include "vv_kernels.h"
 
-// This file is compiled six times: as is (linear volume up to 4 GiB), through vv_raymarch_big.hip
+// This file is compiled seven times: as is (linear volume up to 4 GiB), through vv_raymarch_big.hip
 // with VV_BIG_VOLUME (linear, 64-bit slice addressing), through vv_raymarch_brick.hip with
 // VV_BRICKED (volume sampled from the bricked copy), through vv_raymarch_brick_cached.hip (the same for volumes
 // that live in the caches), through vv_raymarch_zpair.hip with VV_ZPAIR (volume sampled from the z-pair copy) and through
-// vv_raymarch_zfast.hip with VV_ZFAST (f32 volume sampled from the z-fastest copy: side views),
+// vv_raymarch_zfast.hip with VV_ZFAST (volume sampled from the z-fastest copy: side views) and through vv_raymarch_xpair.hip with
+// VV_ZPAIR + VV_XPAIR (the z-pair build on the x-pair copy: side views of small / u8 volumes),
 // so that each path pays only for itself.  The builds for cache-resident volumes (this file as is, z-pair, brick_cached)
 // are compiled with -fno-slp-vectorize: the packed-f32 code the SLP vectoriser makes of the lerps costs a v_mov per
 // operand pair, which VALU-bound frames pay for (C2 -6 %, C1 -4 %, 512^3 -4 %, C2 rotated -6.5 %, Phong -3 ... -6 %),
 // while the builds for volumes beyond the caches are 0.5-3 % (rotated + Phong 9 %) faster with it (Makefile).
-#if defined(VV_ZPAIR)
+#if defined(VV_ZPAIR) && defined(VV_XPAIR)
+#define VV_BIG_NS xpair
+constexpr int kLayout = vv::LAYOUT_ZPAIR;
+#elif defined(VV_ZPAIR)
 #define VV_BIG_NS zpair
 constexpr int kLayout = vv::LAYOUT_ZPAIR;
 #elif defined(VV_BRICKED) && defined(VV_BRICKED_CACHED)
@@ -957,7 +961,9 @@ static void launch_raymarch_impl(const MarchArgs &a, hipStream_t s)
 
 } // namespace VV_BIG_NS
 
-#if defined(VV_ZPAIR)
+#if defined(VV_ZPAIR) && defined(VV_XPAIR)
+void launch_raymarch_xpair(const MarchArgs &a, hipStream_t s) { xpair::launch_raymarch_impl(a, s); }
+#elif defined(VV_ZPAIR)
 void launch_raymarch_zpair(const MarchArgs &a, hipStream_t s) { zpair::launch_raymarch_impl(a, s); }
 #elif defined(VV_BRICKED) && defined(VV_BRICKED_CACHED)
 void launch_raymarch_bricked_cached(const MarchArgs &a, hipStream_t s) { brickc::launch_raymarch_impl(a, s); }
