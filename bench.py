@@ -231,7 +231,34 @@ def main():
         nbricks = int(np.unpackbits(words.view(np.uint8)).sum())
         return ns, nbricks * BRICK ** 3 * vbytes + 4 * W * rows_owned + 4096
 
+    def line_bytes(camera, phong, rays=None, c=None, Wx=None, Hx=None, o=None):
+        """The same frame counted at the granularity the memory system fetches at: distinct 128-byte lines of the layout the frame
+        samples (a) under its executed in-volume samples (`compulsory`: what must cross the L2's memory side at least once) and (b)
+        under every gather the kernel issues, idle lanes and out-of-volume samples included (`issued`); + the frame's own bytes."""
+        c = c or ctx; Wx = Wx or W; Hx = Hx or H; ob = dict(base) if o is None else dict(o)
+        bits = max(c.device_bytes()[:3]) // 128 + 64
+        res = []
+        for every in (False, True):
+            bm = torch.zeros((bits + 31) // 32, dtype=torch.int32, device=dev)
+            io = vv.make_options(touched_lines=bm.data_ptr(), touched_line_bits=bits, touched_lines_all=every, **ob)
+            c.render_device(Wx, Hx, camera, frame.data_ptr() if c is ctx else scratch_frame(Wx, Hx).data_ptr(), options=io, stream=stream, phong=phong, rays=rays)
+            torch.cuda.synchronize()
+            res.append(int(np.unpackbits(bm.cpu().numpy().view(np.uint8)).sum()) * 128 + 4 * Wx * (rows_owned if c is ctx else Hx) + 4096)
+            del bm
+        return {"compulsory_line_bytes": res[0], "issued_line_bytes": res[1]}
+
+    _scratch = {}
+
+    def scratch_frame(Wx, Hx):
+        if (Wx, Hx) not in _scratch:
+            _scratch[(Wx, Hx)] = torch.zeros(Hx * Wx, dtype=torch.int32, device=dev)
+        return _scratch[(Wx, Hx)]
+
     samples, bytes_rank = instrumented(cam, args.phong)
+    try:
+        lines_main = line_bytes(cam, args.phong) if world == 1 else None
+    except Exception as e:                      # an instrument beside the metric: never at its cost
+        lines_main = {"error": f"{type(e).__name__}: {e}"}
     if os.environ.get("VV_STATS"):      # developer statistics from a counters-only frame (no brick marking)
         ctx.render_device(W, H, cam, frame.data_ptr(), options=vv.make_options(count_samples=True, **base), stream=stream, phong=args.phong)
         torch.cuda.synchronize()
@@ -353,6 +380,16 @@ def main():
                      "traffic": traffic, "algorithmic_bytes_per_launch": int(bytes_rank),
                      "bytes_per_sample": round(bytes_rank / max(samples, 1), 3)},
     }
+    if lines_main:
+        out["roofline"].update(lines_main)
+        if traffic and "compulsory_line_bytes" in lines_main:
+            out["roofline"]["traffic_over_compulsory_lines"] = round(traffic / lines_main["compulsory_line_bytes"], 3)
+    # `traffic` counts requests at the L2's memory side; Infinity-Cache (MALL) hits are inside it and no gfx950 counter separates them
+    # (TCC_EA0_RDREQ_DRAM == TCC_EA0_RDREQ on streams that are certainly MALL hits: profiles/r05_mall_reread.txt).  The same file shows why the split
+    # does not matter for this kernel: a re-read served by the MALL costs what a DRAM read costs on that path (6.6 vs 6.2-6.4 TB/s), only an L2 hit is cheap.
+    out["roofline"]["traffic_hbm"] = None
+    out["roofline"]["traffic_hbm_note"] = ("not separable by counters on gfx950 (TCC_EA0_RDREQ_DRAM equals TCC_EA0_RDREQ on certain MALL hits); "
+                                           "re-reads served by the Infinity Cache stream at 6.6-6.8 TB/s against 6.2-6.4 from DRAM (profiles/r05_mall_reread.txt): `traffic` is the figure that bounds the kernel")
     out["roofline"]["traffic_source"] = (f"committed PMC pass (profiles/pmc_traffic.json, taken with csrc {csrc_sha()}: FETCH_SIZE x calibrated factor + WRITE_SIZE, tools/pmc_traffic.py); "
                                          "not measured inside this run") if traffic is not None else "none"
     if traffic_note:
@@ -393,6 +430,10 @@ def main():
                                       "frac": round(by_x / (ms_x * 1e-3) / HBM_PEAK, 4), "traffic": tr_x, "algorithmic_bytes_per_launch": int(by_x)}}
             if note_x:
                 out[name]["roofline"]["traffic_note"] = note_x
+            try:
+                out[name]["roofline"].update(line_bytes(camera, phong))
+            except Exception as e:
+                out[name]["roofline"]["line_bytes_error"] = f"{type(e).__name__}: {e}"
 
         # The call the reference's host makes: runCuda marches from the two first-pass images, drawn at three times the render size
         # (glwidget.cpp:291,358; kernel.cu:317-321).  Images resident in HBM (vv_first_pass on the device), the camera that drew them

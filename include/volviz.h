@@ -147,6 +147,12 @@ typedef struct vv_render_options {
     int      count_samples;  /* 1 => count executed samples (vv_last_sample_count)*/
     uint32_t *touched_bricks;/* device bitmap, 1 bit per 8^3 brick, or NULL:     */
                              /* instrumentation for the roofline's byte model    */
+    /* The same at the granularity the memory system fetches at: 1 bit per 128-byte line of the LAYOUT THE FRAME SAMPLES (bit = byte offset
+     * from that layout's base / 128; vv_device_bytes() bounds the size: the largest resident layout), or NULL.  touched_lines_all = 0 marks
+     * the lines of executed in-volume samples (what must be fetched at least once), 1 the lines of every gather the kernel issues.      */
+    uint32_t *touched_lines;
+    unsigned long long touched_line_bits;   /* size of touched_lines in bits */
+    int      touched_lines_all;
 } vv_render_options;
 
 /* ---- lifecycle ---------------------------------------------------------------- */
@@ -323,23 +329,11 @@ int  vv_device_bytes(const vv_context *ctx, unsigned long long out[4]);
 /* ---- metrics (the reference only has a clock() overlay) ---------------- */
 float              vv_last_frame_ms(const vv_context *ctx);      /* hipEvent time of the last vv_render */
 unsigned long long vv_last_sample_count(vv_context *ctx);        /* executed samples, if count_samples */
-int                vv_build_is_experimental(void);   /* 0: the product library; 1: libvolviz_hip_x.so, built with -DVV_EXPERIMENTAL, which adds the opt-in kernels
-                                                      * behind VV_SKEW / VV_SWEEP / VV_PHONG2 (bit-identical, never faster; volume-viz_amd/Makefile) */
 int                vv_debug_last_launch(vv_context *ctx, int out[8]);  /* what the launch policy chose for the last vv_render (developer aid): wave tile log2 width,
                                                                        * block log2 width, samples per trip, LDS reserve, layout (0 linear, 1 linear/64-bit, 2 bricked,
-                                                                       * 3 z-pair), view known to the policy (0 / 1), density x 1000, Phong (0 / 1) */
-int                vv_debug_counters(vv_context *ctx, unsigned long long out[16]);  /* developer statistics of the last instrumented frame; after ANY frame of the
-                                                                                     * opt-in sweep kernel out[7] is valid: bits 0..47 non-zero = the frame is not trustworthy
-                                                                                     * (a synchronous vv_render returns VV_ERR_DEVICE for it by itself) */
-/* developer trace of the sweep kernel's blocks of the last frame rendered with VV_SWEEP_TRACE=1 in the environment:
- * 8 words per block (start, march start, end in 10 ns ticks; hardware ids; tile; slice range; chunks; valid).
- * Returns the number of blocks copied. */
-int                vv_debug_sweep_trace(vv_context *ctx, unsigned long long *out, int max_blocks);
-/* The slab-sweep planner on its own (host arithmetic, no device): would this frame qualify for vv_sweep.hip's kernel and
- * with which tile / LDS image sizes?  out = {enabled, major (1 = y, 2 = z), sgn, wx, wy, pxc, ry, group, ring, ntx, nty, nl}. */
-int                vv_debug_plan_sweep(int width, int height, const struct camera_params *camera, const vv_ray_source *rays,
-                                       const float step[3], int voxel_type, int nx, int ny, int nz, int phong, int slice_type,
-                                       int out[12]);
+                                                                       * 3 z-pair, 4 z-fastest, 5 x-pair), view known to the policy (0 / 1), density x 1000, Phong (0 / 1) */
+int                vv_debug_counters(vv_context *ctx, unsigned long long out[16]);  /* developer statistics of the last instrumented frame: [0] executed samples,
+                                                                                     * [1] lane slots spent, [2] / [3] waves that sampled the bricked / a pair copy */
 /* The VV_* developer knobs of the environment are read when a context is created and at every volume load, never
  * per frame; this reads them again (tests that flip a knob between two frames of one volume). */
 int                vv_reread_env(vv_context *ctx);

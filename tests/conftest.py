@@ -46,16 +46,3 @@ def ctx():
     yield c
     c.close()
 
-
-@pytest.fixture(scope="session")
-def xctx():
-    """A context on the experimental build of the library (libvolviz_hip_x.so: the product's sources with -DVV_EXPERIMENTAL), which adds
-    the opt-in kernels behind VV_SKEW / VV_SWEEP / VV_PHONG2.  They are bit-identical to the defaults and slower; the tests that pin
-    them run against this library, the product ships without them."""
-    import volviz_amd as vv
-    if not os.path.exists(vv.LIB_X_PATH):
-        subprocess.check_call(["make", "-C", os.path.join(REPO, "volume-viz_amd"), "lib/libvolviz_hip_x.so"], stdout=subprocess.DEVNULL)
-    c = vv.Context(0, lib_path=vv.LIB_X_PATH)
-    assert c.lib.vv_build_is_experimental() == 1
-    yield c
-    c.close()

@@ -463,76 +463,19 @@ def test_render_interleaved_shards(ctx, W, H):
             assert_frames_close(got, want)
 
 
-SWEEP_CAMS = {
-    "z+": vv.Camera(),                                                             # along +z (the headline view)
-    "z-": vv.Camera(origin=(0.3, 0.2, 4.0)),                                       # along -z
-    "y+": vv.Camera(origin=(0.5, -3.5, 0.4), up=(0.0, 0.0, 1.0)),                  # along +y: slices are x-z planes
-    "y-": vv.Camera(origin=(-0.3, 3.8, -0.2), up=(0.0, 0.0, 1.0)),
-    "tilt": vv.Camera.orbit(4.0, 1.2, -1.3),                                       # z+ with both minor slopes
-}
-
-
-@pytest.mark.parametrize("view", list(SWEEP_CAMS))
-def test_sweep_kernel_is_bit_identical(xctx, view, monkeypatch):
-    """The slab sweep (vv_sweep.hip: volume streamed through an LDS slice ring, every wave copies and marches; VV_SWEEP=1
-    forces it wherever it qualifies) must give the oracle's frames and sample counts: both sweep axes and
-    directions, ragged volume sizes, both ERT modes and filters, scaled cubes, sharded rows; the instrumented
-    build also checks that no sample fell outside the slices' images in LDS and that no watchdog fired."""
-    ctx = xctx                      # the experimental build of the library: the product does not ship the opt-in kernels
-    monkeypatch.setenv("VV_SWEEP", "1")
-    cam = SWEEP_CAMS[view]
-    cases = (((64, 64, 64), vv.TF_ENGINE, 1 / 64, 150, 97), ((48, 40, 36), vv.TF_HEAD, 1 / 50, 150, 97),
-             ((36, 70, 20), vv.TF_ENGINE, 1 / 40, 97, 150), ((128, 128, 128), vv.TF_ENGINE, 1 / 128, 320, 200),
-             ((20, 16, 200), vv.TF_HEAD, 1 / 100, 64, 48))
-    for dims, tfp, step, W, H in cases:
-        vol = (O.noise_u8(*dims, 7) if dims[0] != 128 else O.draw_default_brain(*dims)).astype(np.float32) / np.float32(255)
-        tf = vv.transfer_preset(tfp)
-        ctx.load_volume(vol, tf)
-        for ert, filt in ((vv.ERT_REFERENCE, vv.FILTER_TEX8), (vv.ERT_TRUE, vv.FILTER_EXACT)):
-            o = dict(step=step, ert_mode=ert, ert_threshold=0.9, filter=filt)
-            got = ctx.render(W, H, cam, options=vv.make_options(count_samples=True, **o), fill=0x11)
-            n_got = ctx.last_sample_count()
-            cnt = ctx.debug_counters()
-            want, n = O.render(vol, tf, W, H, cam, options=vv.make_options(**o), fill=0x11)
-            what = f"sweep {view} {dims} step {step:.4f} ert{ert} filt{filt}"
-            # (the thin 20 x 16 x 200 volume qualifies only along z: in voxel units its rays are too flat along y)
-            # (the ragged volumes qualify only for some views: in voxel units their rays may be too flat along the sweep axis)
-            assert cnt[5] > 0 or n == 0 or dims[0] != dims[2], f"{what}: the sweep kernel did not run"
-            assert cnt[4] == 0 and (int(cnt[7]) & 0xFFFFFFFFFFFF) == 0, f"{what}: {cnt[4]} samples outside the LDS images, error counts {int(cnt[7]):#x}"   # (bits 48+: blocks that left the ring for gathers -- a statistic)
-            assert_frames_close(got, want, what)
-            assert n_got == n, what
-            got2 = ctx.render(W, H, cam, options=vv.make_options(**o), fill=0x11)            # the uninstrumented build
-            assert np.array_equal(got2, want), what + " (uninstrumented)"
-    # scaled cube and a shard of the frame
-    vol = O.noise_u8(40, 56, 48, 3).astype(np.float32) / np.float32(255)
-    tf = vv.transfer_preset(vv.TF_ENGINE)
-    ctx.load_volume(vol, tf)
-    cam_s = vv.Camera(origin=cam.origin, up=cam.up, scale=(0.8, 1.0, 1.57))
-    for shard in (None, (4, 3, 1)):
-        o = vv.make_options(step=1 / 64, count_samples=True, shard=shard)
-        got = ctx.render(200, 160, cam_s, options=o, fill=0x22)
-        n_got = ctx.last_sample_count()
-        cnt = ctx.debug_counters()
-        want, n = O.render(vol, tf, 200, 160, cam_s, options=o, fill=0x22)
-        assert cnt[4] == 0 and (int(cnt[7]) & 0xFFFFFFFFFFFF) == 0
-        assert_frames_close(got, want, f"sweep {view} scaled shard={shard}")
-        assert n_got == n
-
-
 @pytest.mark.parametrize("phong", [False, True])
-def test_tables_with_opacity_outside_unit_interval(xctx, phong, monkeypatch):
+def test_tables_with_opacity_outside_unit_interval(ctx, phong, monkeypatch):
     """A table whose opacities exceed 1 (or are negative) makes the accumulated opacity non-monotone: a ray that passed
     the ERT threshold can fall back under it, and the reference's per-sample test (kernel.cu:272-274) then composites more
     than one sample in later chunks.  The kernels' one-sample-per-chunk shortcuts (pin 4, the depth-limited Phong
-    refresh) apply only to tables with opacities in [0, 1]; every layout and the sweep kernel must match the oracle."""
-    ctx = xctx                      # the experimental build of the library: the product does not ship the opt-in kernels
+    refresh) apply only to tables with opacities in [0, 1]; every layout must match the oracle."""
     rng = np.random.default_rng(4242)
     vol = O.noise_u8(40, 36, 44, 11).astype(np.float32) / np.float32(255)
     for k, (lo, hi) in enumerate(((0.0, 2.5), (-0.5, 1.8), (0.0, 1.0))):
         tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
         tf[:, 3] = rng.uniform(lo, hi, 256).astype(np.float32)
-        for env in ({}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_SWEEP": "1"}, {"VV_SKEW": "3"}, {"VV_SKEW": "1", "VV_UNROLL": "1"}):
-            for name in ("VV_BRICKED", "VV_ZPAIR", "VV_SWEEP", "VV_SKEW", "VV_UNROLL"):
+        for env in ({}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_ZFAST": "1"}, {"VV_FORCE_BIG": "1"}, {"VV_UNROLL": "2"}):
+            for name in ("VV_BRICKED", "VV_ZPAIR", "VV_ZFAST", "VV_FORCE_BIG", "VV_UNROLL"):
                 monkeypatch.delenv(name, raising=False)
             for name, val in env.items():
                 monkeypatch.setenv(name, val)
@@ -567,11 +510,10 @@ def test_sharded_phong_frame_whose_height_is_1_mod_14(ctx):
 
 
 @pytest.mark.parametrize("first", range(0, 200, 50))
-def test_wild_fuzz_subset(xctx, first, monkeypatch):
+def test_wild_fuzz_subset(ctx, first, monkeypatch):
     """200 cases of tools/fuzz_wild.py (degenerate volume shapes, tables with colours and opacities outside [0, 1], eyes
     inside the cube, extreme scales, steps and thresholds, shards; every layout and launch form in turn): frames and
     sample counts equal the oracle's.  The tool itself ran seeds 0..2999 on MI355X without a mismatch."""
-    ctx = xctx                      # the experimental build of the library: the product does not ship the opt-in kernels
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_wild", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_wild.py"))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
@@ -589,89 +531,6 @@ def test_wild_fuzz_subset(xctx, first, monkeypatch):
         what = f"wild seed {seed}: {vol.shape} {vol.dtype} {W}x{H} phong={phong} {o}"
         assert_frames_close(got, want, what)
         assert n_got is None or n_got == n, what
-
-
-def test_sweep_tile_wider_than_the_frame(xctx, monkeypatch):
-    """A frame narrower than a sweep tile (96 x 8 pixels): the tile's frustum must be taken over the pixels that exist.
-    Beyond the frame's edge the rays' slope against the sweep axis can change sign (a thin, strongly scaled cube seen
-    from the side), and the slopes of the four tile corners then bound nothing: the footprints missed the volume and
-    the uninstrumented build rendered wrong pixels without a word (found by tools/fuzz_wild.py, seed 78805)."""
-    ctx = xctx                      # the experimental build of the library: the product does not ship the opt-in kernels
-    monkeypatch.setenv("VV_SWEEP", "1")
-    rng = np.random.default_rng(5)
-    vol = rng.random((31, 5, 4), dtype=np.float32)
-    tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
-    for origin, scale, W, H in (((-1.4479461520329102, 0.0, 1.3796564575332109), (0.1, 0.5, 0.5), 52, 54),
-                                ((1.2, 0.3, 1.6), (0.1, 0.5, 0.5), 40, 70), ((-0.9, 0.2, -2.2), (0.2, 1.0, 0.5), 30, 30)):
-        cam = vv.Camera(origin=origin, scale=scale)
-        o = dict(step=1 / 64, filter=vv.FILTER_EXACT, ert_threshold=1.5)
-        ctx.load_volume(vol, tf)
-        got = ctx.render(W, H, cam, options=vv.make_options(count_samples=True, **o), fill=0x3C)
-        n_got = ctx.last_sample_count()
-        cnt = ctx.debug_counters()
-        want, n = O.render(vol, tf, W, H, cam, options=vv.make_options(**o), fill=0x3C)
-        what = f"eye {origin} scale {scale} {W}x{H}"
-        assert cnt[4] == 0 and (int(cnt[7]) & 0xFFFFFFFFFFFF) == 0, f"{what}: {cnt[4]} samples outside the LDS images, error counts {int(cnt[7]):#x}"
-        assert_frames_close(got, want, what)
-        assert n_got == n, what
-        got2 = ctx.render(W, H, cam, options=vv.make_options(**o), fill=0x3C)
-        assert np.array_equal(got2, want), what + " (uninstrumented)"
-
-
-def _sweep_case(rng):
-    n = 4 * int(rng.integers(3, 18))
-    dims = (n, n, n) if rng.random() < 0.5 else (4 * int(rng.integers(3, 18)), int(rng.integers(12, 72)), int(rng.integers(12, 72)))
-    W = int(rng.choice([int(rng.integers(2, 260)), 29, 97, 193])); H = int(rng.choice([int(rng.integers(2, 200)), 29, 57]))
-    axis = int(rng.integers(0, 4))                                  # +z, -z, +y, -y
-    r = float(rng.uniform(2.6, 5.0)); t1, t2 = (float(v) for v in rng.uniform(-0.35, 0.35, size=2))
-    if axis < 2:
-        cam = vv.Camera(origin=(r * t1, r * t2, (-1.0 if axis == 0 else 1.0) * r), up=(0.0, 1.0, 0.0))
-    else:
-        cam = vv.Camera(origin=(r * t1, (-1.0 if axis == 2 else 1.0) * r, r * t2), up=(0.0, 0.0, 1.0))
-    step = float(rng.choice([1 / 16, 1 / 37, 1 / 64, 1 / 130]))
-    return dims, W, H, cam, step
-
-
-@pytest.mark.parametrize("seed", range(24))
-def test_sweep_kernel_seeded(xctx, seed, monkeypatch):
-    """Seeded cases for the slab sweep, like test_render_random_sweep but drawn (by rejection against the host-side
-    planner, vv_debug_plan_sweep) from what the sweep accepts: f32, unshaded, no cutting plane, 16-byte rows, eye
-    outside the cube roughly along +-y or +-z with a random tilt, samples at most 3 slices apart.  Random volume
-    shapes and content, tables, frame sizes, steps, filters, ERT modes and thresholds: frames and sample counts
-    equal the oracle's, and the instrumented build confirms the sweep kernel is what ran."""
-    ctx = xctx                      # the experimental build of the library: the product does not ship the opt-in kernels
-    monkeypatch.setenv("VV_SWEEP", "1")
-    rng = np.random.default_rng(7000 + seed)
-    for _ in range(64):
-        dims, W, H, cam, step = _sweep_case(rng)
-        if vv.plan_sweep(W, H, cam, step, vv.VOXEL_F32, dims)["enabled"]:
-            break
-    else:
-        pytest.fail("no case the planner accepts in 64 draws")
-    kind = seed % 3
-    vol = (O.draw_default_brain(*dims) if kind == 0 else O.noise_u8(*dims, int(rng.integers(1, 2**31))) if kind == 1
-           else rng.integers(0, 256, size=dims[::-1], dtype=np.uint8)).astype(np.float32) / np.float32(255)
-    if rng.random() < 0.3:
-        vol = (vol * np.float32(1.3) - np.float32(0.1)).astype(np.float32)
-    if rng.random() < 0.5:
-        tf = vv.transfer_preset(int(rng.choice([vv.TF_ENGINE, vv.TF_HEAD, vv.TF_MRI])))
-    else:
-        tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
-        tf[:, 3] *= np.float32(rng.choice([0.03, 0.2, 1.0]))
-    o = dict(step=step, filter=int(rng.choice([vv.FILTER_TEX8, vv.FILTER_EXACT])),
-             ert_mode=int(rng.choice([vv.ERT_REFERENCE, vv.ERT_TRUE])), ert_threshold=float(rng.choice([0.95, 0.5, 0.999])))
-    ctx.load_volume(vol, tf)
-    got = ctx.render(W, H, cam, options=vv.make_options(count_samples=True, **o), fill=0x3C)
-    n_got = ctx.last_sample_count()
-    cnt = ctx.debug_counters()
-    want, n_want = O.render(vol, tf, W, H, cam, options=vv.make_options(**o), fill=0x3C)
-    what = f"sweep seed {seed}: {vol.shape} {W}x{H} eye {tuple(round(v, 2) for v in cam.origin)} {o}"
-    assert cnt[5] > 0, f"{what}: the planner accepted the frame but the sweep kernel staged nothing"
-    assert cnt[4] == 0 and (int(cnt[7]) & 0xFFFFFFFFFFFF) == 0, f"{what}: {cnt[4]} samples outside the LDS images, error counts {int(cnt[7]):#x}"
-    assert_frames_close(got, want, what)
-    assert n_got == n_want, what
-    got2 = ctx.render(W, H, cam, options=vv.make_options(**o), fill=0x3C)                  # the uninstrumented build
-    assert np.array_equal(got2, want), what + " (uninstrumented)"
 
 
 def test_phong_forced_on_the_random_cases(ctx):
@@ -702,103 +561,14 @@ def test_phong_forced_on_the_random_cases(ctx):
             assert n_got == n
 
 
-PHONG_FORMS = [{"VV_PHONG2": "1"}, {"VV_PHONG2": "2"}, {"VV_PHONG_PAIR": "1"}, {"VV_PHONG2": "1", "VV_BRICKED": "1"}, {"VV_PHONG_PAIR": "1", "VV_FORCE_BIG": "1"},
-               {"VV_PHONG2": "2", "VV_BRICKED": "1"}]
-
-
-@pytest.mark.parametrize("form", range(len(PHONG_FORMS)))
-def test_experimental_phong_forms_are_bit_identical(xctx, form, monkeypatch):
-    """The Phong march's rebuilt forms of round 4 (experimental build only: march_phong2_kernel with one / two slabs per block -- batched, packed-fp32
-    shading, division cores, eight post-ERT chunks per barrier pair -- and march_phong_pair_kernel, the first kernel with two slabs per block): the
-    random cases with Phong forced on (cutting planes, both ERT modes and filters, odd frame widths, tables with any opacity), a mid-size frame on both
-    cameras and a sharded one, instrumented and not -- same frames, same sample counts as the oracle.  None of them is faster than march_phong_kernel
-    (profiles/r04_phong_forms.txt); the test keeps the record of that result honest."""
-    ctx = xctx
-    for k, v in PHONG_FORMS[form].items():
-        monkeypatch.setenv(k, v)
-    for seed in range(form, 48, 6):
-        vol, tf, W, H, cam, sp, _, o = _random_case(seed)
-        ctx.load_volume(vol, tf)
-        opts = vv.make_options(**o)
-        got = ctx.render(W, H, cam, slice=sp, phong=True, options=opts, fill=0x3C)
-        n_got = ctx.last_sample_count()
-        want, n = O.render(vol, tf, W, H, cam, slice=sp, phong=True, options=opts, fill=0x3C)
-        what = f"{PHONG_FORMS[form]} seed {seed}: {vol.shape} {vol.dtype} {W}x{H} {o}"
-        assert_frames_close(got, want, what)
-        assert n_got == n, what
-        o2 = dict(o); o2["count_samples"] = False
-        assert np.array_equal(ctx.render(W, H, cam, slice=sp, phong=True, options=vv.make_options(**o2), fill=0x3C), got), what + " (uninstrumented)"
-    vol = O.draw_default_brain(64, 64, 64)
-    tf = vv.transfer_preset(vv.TF_ENGINE)
-    ctx.load_volume(vol, tf)
-    for W, H, shard in ((170, 170, None), (43, 57, None), (300, 200, (4, 3, 1))):
-        o = vv.make_options(count_samples=True, shard=shard)
-        for cam in (_cam("a"), _cam("b")):
-            got = ctx.render(W, H, cam, phong=True, options=o, fill=7)
-            n_got = ctx.last_sample_count()
-            want, n = O.render(vol, tf, W, H, cam, phong=True, options=o, fill=7)
-            assert_frames_close(got, want, f"{PHONG_FORMS[form]} {W}x{H} shard={shard}")
-            assert n_got == n
-
-
-SKEW_ENVS = [{"VV_SKEW": "3"}, {"VV_SKEW": "1", "VV_UNROLL": "1"}, {"VV_SKEW": "2", "VV_UNROLL": "2"}, {"VV_SKEW": "3", "VV_FORCE_BIG": "1"},
-             {"VV_SKEW": "3", "VV_ZPAIR": "1"}, {"VV_SKEW": "2", "VV_BRICKED": "1"}]
-
-
-@pytest.mark.parametrize("seed", range(48))
-def test_skewed_lock_step_is_bit_identical(xctx, seed, monkeypatch):
-    """march_skew_kernel (lanes of a wave offset in sample index so that they sit on the same slices; VV_SKEW forces it and
-    its axis): the sweep's unshaded cases -- cutting planes, both ERT modes, scaled cubes, tables with any opacity -- on every
-    layout and with 1, 2 and 3 samples per trip, instrumented and not: same frames, same sample counts as the oracle."""
-    ctx = xctx                      # the experimental build of the library: the product does not ship the opt-in kernels
-    for k, v in SKEW_ENVS[seed % len(SKEW_ENVS)].items():
-        monkeypatch.setenv(k, v)
-    vol, tf, W, H, cam, sp, _, o = _random_case(seed)
-    ctx.load_volume(vol, tf)
-    opts = vv.make_options(**o)
-    got = ctx.render(W, H, cam, slice=sp, options=opts, fill=0x3C)
-    n_got = ctx.last_sample_count()
-    want, n = O.render(vol, tf, W, H, cam, slice=sp, options=opts, fill=0x3C)
-    what = f"skew seed {seed} {SKEW_ENVS[seed % len(SKEW_ENVS)]}: {vol.shape} {vol.dtype} {W}x{H} {o}"
-    assert_frames_close(got, want, what)
-    assert n_got == n, what
-    o2 = dict(o); o2["count_samples"] = False
-    got2 = ctx.render(W, H, cam, slice=sp, options=vv.make_options(**o2), fill=0x3C)
-    assert np.array_equal(got2, want), what + " (uninstrumented)"
-
-
-def test_skewed_lock_step_larger_frames(xctx, monkeypatch):
-    """The same on frames where a wave's lanes really differ in depth (wide fields of view close to the cube, long rays)."""
-    ctx = xctx                      # the experimental build of the library: the product does not ship the opt-in kernels
-    monkeypatch.setenv("VV_SKEW", "3")
-    vol = O.noise_u8(96, 80, 112, 5).astype(np.float32) / np.float32(255)
-    tf = vv.transfer_preset(vv.TF_ENGINE)
-    ctx.load_volume(vol, tf)
-    for cam, W, H, step in ((vv.Camera(), 320, 200, 1 / 200), (vv.Camera.orbit(2.2, 1.2, -1.3), 257, 131, 1 / 150),
-                            (vv.Camera.orbit(1.9, 0.3, 0.4, scale=(0.8, 1.0, 1.57)), 200, 160, 1 / 90)):
-        for ert in (vv.ERT_REFERENCE, vv.ERT_TRUE):
-            for st in (vv.SLICE_NONE, vv.SLICE_PLANE, vv.SLICE_PLANE_CUT):
-                sp = vv.make_slice_params(st, (0.45, 0.5, 0.55), (0.3, -0.2, 1.0))
-                o = dict(step=step, ert_mode=ert, ert_threshold=0.9, count_samples=True)
-                got = ctx.render(W, H, cam, slice=sp, options=vv.make_options(**o), fill=0x11)
-                n_got = ctx.last_sample_count()
-                want, n = O.render(vol, tf, W, H, cam, slice=sp, options=vv.make_options(**o), fill=0x11)
-                what = f"skew {W}x{H} step {step:.4f} ert{ert} slice{st}"
-                assert_frames_close(got, want, what)
-                assert n_got == n, what
-
-
 @pytest.mark.parametrize("seed", range(0, 48, 2))
-def test_block_shapes_are_bit_identical(xctx, seed, monkeypatch):
-    """march_kernel / march_skew_kernel with the block's four 32 x 2 (or 16 x 4) wave tiles stacked (32 x 8 pixels), 2 x 2 (64 x 4: the policy for sparse
+def test_block_shapes_are_bit_identical(ctx, seed, monkeypatch):
+    """march_kernel with the block's four 32 x 2 (or 16 x 4) wave tiles stacked (32 x 8 pixels), 2 x 2 (64 x 4: the policy for sparse
     frames of big volumes) or side by side (128 x 2), and its four 8 x 8 tiles 2 x 2 (16 x 16) or stacked (8 x 32) instead of side by side; strips are as high as the block.  Forced on the small random cases, whole frames, cropped slab
     rows and interleaved shards: same frames, same sample counts."""
-    ctx = xctx                      # the experimental build of the library: the product does not ship the opt-in kernels
     monkeypatch.setenv("VV_BLOCK_W", ("64", "128", "64")[seed % 3])
     monkeypatch.setenv("VV_TILE_LOG2W", "4" if seed % 6 == 4 else "5")
-    if seed % 8 == 2:
-        monkeypatch.setenv("VV_SKEW", "3")
-    elif (seed // 2) % 4 >= 2:        # 8 x 8 wave tiles: 16 x 16 / 8 x 32 blocks (strips higher than 8 rows), linear and bricked
+    if (seed // 2) % 4 >= 2:        # 8 x 8 wave tiles: 16 x 16 / 8 x 32 blocks (strips higher than 8 rows), linear and bricked
         monkeypatch.setenv("VV_TILE_LOG2W", "3"); monkeypatch.setenv("VV_BLOCK_W", ("16", "8")[(seed // 8) % 2])
         if seed % 3 != 1:
             monkeypatch.setenv("VV_BRICKED", "1")
@@ -1505,3 +1275,39 @@ def test_errors_are_codes(ctx):
     with pytest.raises(vv.VolvizError):
         c2.render(8, 8, vv.Camera(scale=(0, 1, 1)))
     c2.close()
+
+
+def test_touched_lines_instrument(ctx, monkeypatch):
+    """vv_render_options::touched_lines (the roofline's line-granular byte count): a 32^3 f32 volume has rows of exactly one 128-byte line;
+    a frame whose samples cover every voxel must mark every line of the volume (+ at most the zero padding's rows that the weight-0 corners
+    of edge samples read), the `issued` set contains the `compulsory` one, both layouts agree on the frame, and the bricked copy's lines
+    (320-byte bricks) are counted from that copy's own addresses."""
+    import torch
+    n = 32
+    vol = O.noise_u8(n, n, n, 3).astype(np.float32) / np.float32(255)
+    tf = vv.transfer_preset(vv.TF_HEAD)                        # low opacity: no ray terminates early
+    W = H = 300
+    cam = vv.Camera(origin=(0.0, 0.0, -3.0))
+    dev = torch.device("cuda", 0)
+    frame = torch.zeros(H * W, dtype=torch.int32, device=dev)
+    counts = {}
+    for env in ({"VV_BRICKED": "0"}, {"VV_BRICKED": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx.load_volume(vol, tf)
+        ctx.render_device(W, H, cam, frame.data_ptr(), options=vv.make_options(step=1 / 128))       # (builds the copy)
+        bits = max(ctx.device_bytes()[:3]) // 128 + 64
+        got = []
+        for every in (False, True):
+            bm = torch.zeros((bits + 31) // 32, dtype=torch.int32, device=dev)
+            o = vv.make_options(step=1 / 128, touched_lines=bm.data_ptr(), touched_line_bits=bits, touched_lines_all=every)
+            ctx.render_device(W, H, cam, frame.data_ptr(), options=o)
+            torch.cuda.synchronize()
+            got.append(np.unpackbits(bm.cpu().numpy().view(np.uint8)))
+        assert np.all(got[1] >= got[0]), env                                   # issued contains compulsory
+        counts[env["VV_BRICKED"]] = int(got[0].sum())
+        assert ctx.last_launch()["layout"] == (2 if env["VV_BRICKED"] == "1" else 0)
+    vol_lines = n * n * n * 4 // 128                                           # 1024: one line per row
+    assert vol_lines <= counts["0"] <= vol_lines + n + 4, counts                # every row of the volume + at most the first padding slice's rows (weight-0 corners)
+    brick_lines = (n // 4) ** 3 * 320 // 128                                    # 1280
+    assert brick_lines <= counts["1"] <= brick_lines + 2 * (n // 4) * (n // 4 + 1) * 3 + 64, counts      # every brick + at most the clamped extra layers in y and z

@@ -198,36 +198,6 @@ def test_camera_controls_match_matrix_form():
         vv.camera_orbit_drag((0, 0, 0), 1, 1)
 
 
-def test_sweep_planner_decisions():
-    """The slab-sweep planner (vv_debug_plan_sweep: host arithmetic only): which frames qualify for the LDS-streamed
-    march, along which axis, and that the LDS image it sizes grows with the pixel footprint."""
-    n = 1024
-    c3 = vv.plan_sweep(1920, 1080, vv.Camera(), 1 / 512, vv.VOXEL_F32, (n, n, n))
-    assert c3["enabled"] == 1 and c3["major"] == 2 and c3["sgn"] == 1            # the headline view sweeps +z
-    assert c3["wx"] * c3["wy"] + c3["nl"] <= 16 and 1 <= c3["group"] <= 8
-    assert 3 <= c3["pxc"] <= 8 and 8 <= c3["ry"] <= 60
-    assert c3["ntx"] * 32 * c3["wx"] >= 1920 and c3["nty"] * 2 * c3["wy"] >= 1078
-    back = vv.plan_sweep(1920, 1080, vv.Camera(origin=(0.3, 0.2, 4.0)), 1 / 512, vv.VOXEL_F32, (n, n, n))
-    assert back["enabled"] == 1 and back["major"] == 2 and back["sgn"] == -1
-    ycam = vv.Camera(origin=(0.5, -3.5, 0.4), up=(0.0, 0.0, 1.0))
-    yy = vv.plan_sweep(1280, 720, ycam, 1 / 512, vv.VOXEL_F32, (n, n, n))
-    assert yy["enabled"] == 1 and yy["major"] == 1 and yy["sgn"] == 1
-    # a denser frame of the same volume needs a smaller image per slice
-    dense = vv.plan_sweep(3840, 2160, vv.Camera(), 1 / 1024, vv.VOXEL_F32, (n, n, n))
-    assert dense["enabled"] == 1 and dense["pxc"] <= c3["pxc"] and dense["ry"] <= c3["ry"]
-    # frames that must stay on the gather kernels
-    assert vv.plan_sweep(1920, 1080, vv.Camera(), 1 / 512, vv.VOXEL_U8, (n, n, n))["enabled"] == 0          # u8
-    assert vv.plan_sweep(1920, 1080, vv.Camera(), 1 / 512, vv.VOXEL_F32, (n, n, n), phong=True)["enabled"] == 0
-    assert vv.plan_sweep(1920, 1080, vv.Camera(), 1 / 512, vv.VOXEL_F32, (n, n, n), slice_type=vv.SLICE_PLANE)["enabled"] == 0
-    assert vv.plan_sweep(1920, 1080, vv.Camera(), (1 / 512, 1 / 256, 1 / 512), vv.VOXEL_F32, (n, n, n))["enabled"] == 0   # anisotropic step
-    assert vv.plan_sweep(1920, 1080, vv.Camera(), 1 / 64, vv.VOXEL_F32, (n, n, n))["enabled"] == 0           # 16 slices per sample
-    assert vv.plan_sweep(1920, 1080, vv.Camera(origin=(4.0, 0.1, 0.1)), 1 / 512, vv.VOXEL_F32, (n, n, n))["enabled"] == 0   # along x
-    assert vv.plan_sweep(1920, 1080, vv.Camera(origin=(0.1, 0.1, -0.5)), 1 / 512, vv.VOXEL_F32, (n, n, n))["enabled"] == 0  # eye in the cube
-    rs = vv.analytic_rays(vv.Camera(), quantize8=True)
-    assert vv.plan_sweep(1920, 1080, vv.Camera(), 1 / 512, vv.VOXEL_F32, (n, n, n), rays=rs)["enabled"] == 0
-    assert vv.plan_sweep(1920, 1080, vv.Camera(), 1 / 512, vv.VOXEL_F32, (1023, n, n))["enabled"] == 0     # rows not 16-byte aligned
-
-
 def test_developer_tools_parse():
     """tools/ holds the developer aids the profiles under profiles/ were taken with (they run on the GPU box).  None of them is part of the product;
     this keeps them from rotting silently: every Python tool compiles, every shell tool passes `bash -n`, and no tool names a `VV_*` knob the library

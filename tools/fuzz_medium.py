@@ -43,9 +43,9 @@ def main():
     bad = 0
     used = {"bricks": 0, "zpair": 0}
     knobs = os.environ.get("FUZZ_KNOBS") == "1"
-    KNOBS = ("VV_BRICKED", "VV_ZPAIR", "VV_FORCE_BIG", "VV_PITCH_FORCE", "VV_SWEEP", "VV_SKEW", "VV_UNROLL")
-    ENVS = [{"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_FORCE_BIG": "1"}, {"VV_PITCH_FORCE": "1"}, {"VV_SWEEP": "1"}, {"VV_SKEW": "3"},
-            {"VV_SKEW": "3", "VV_UNROLL": "1"}, {"VV_SKEW": "2", "VV_BRICKED": "1"}, {"VV_BRICKED": "0"}, {"VV_FORCE_BIG": "1", "VV_BRICKED": "1"}]
+    KNOBS = ("VV_BRICKED", "VV_ZPAIR", "VV_ZFAST", "VV_FORCE_BIG", "VV_PITCH_FORCE", "VV_UNROLL")
+    ENVS = [{"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_FORCE_BIG": "1"}, {"VV_PITCH_FORCE": "1"}, {"VV_ZFAST": "1"}, {"VV_UNROLL": "2"},
+            {"VV_UNROLL": "3", "VV_BRICKED": "1"}, {"VV_ZFAST": "1", "VV_ZPAIR": "0"}, {"VV_BRICKED": "0"}, {"VV_FORCE_BIG": "1", "VV_BRICKED": "1"}]
     for seed in range(lo, hi):
         vol, tf, W, H, cam, sp, phong, o = case(seed)
         if knobs:

@@ -9,10 +9,10 @@ import torch  # noqa: F401  (its HIP runtime first)
 import oracle_lib as O
 import volviz_amd as vv
 
-KNOBS = ("VV_ZFAST", "VV_BRICKED", "VV_ZPAIR", "VV_FORCE_BIG", "VV_PITCH_FORCE", "VV_SWEEP", "VV_SKEW", "VV_UNROLL", "VV_SWEEP_STEPS", "VV_SWEEP_WX", "VV_SWEEP_WY", "VV_BLOCK_W", "VV_TILE_LOG2W", "VV_TAIL")
-ENVS = [{}, {"VV_ZFAST": "1"}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_FORCE_BIG": "1"}, {"VV_PITCH_FORCE": "1"}, {"VV_SWEEP": "1"}, {"VV_SKEW": "3"},
-        {"VV_SKEW": "2", "VV_UNROLL": "1"}, {"VV_SKEW": "1", "VV_UNROLL": "2", "VV_FORCE_BIG": "1"}, {"VV_SKEW": "3", "VV_ZPAIR": "1"}, {"VV_SKEW": "3", "VV_BRICKED": "1"},
-        {"VV_BLOCK_W": "64", "VV_TILE_LOG2W": "5"}, {"VV_BLOCK_W": "128", "VV_TILE_LOG2W": "5", "VV_SKEW": "3"}, {"VV_SWEEP": "1", "VV_SWEEP_STEPS": "2"}, {"VV_SWEEP": "1", "VV_SWEEP_WX": "1", "VV_SWEEP_WY": "3"}, {"VV_TAIL": "0"}, {"VV_BLOCK_W": "16", "VV_TILE_LOG2W": "3"}]
+KNOBS = ("VV_ZFAST", "VV_BRICKED", "VV_ZPAIR", "VV_FORCE_BIG", "VV_PITCH_FORCE", "VV_UNROLL", "VV_BLOCK_W", "VV_TILE_LOG2W", "VV_TAIL")
+ENVS = [{}, {"VV_ZFAST": "1"}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_FORCE_BIG": "1"}, {"VV_PITCH_FORCE": "1"}, {"VV_UNROLL": "2"}, {"VV_UNROLL": "3", "VV_BRICKED": "1"},
+        {"VV_ZFAST": "1", "VV_ZPAIR": "0"}, {"VV_UNROLL": "2", "VV_FORCE_BIG": "1"}, {"VV_BRICKED": "0"}, {"VV_FORCE_BIG": "1", "VV_BRICKED": "1"},
+        {"VV_BLOCK_W": "64", "VV_TILE_LOG2W": "5"}, {"VV_BLOCK_W": "128", "VV_TILE_LOG2W": "5"}, {"VV_BLOCK_W": "8", "VV_TILE_LOG2W": "3", "VV_BRICKED": "1"}, {"VV_TILE_LOG2W": "4"}, {"VV_TAIL": "0"}, {"VV_BLOCK_W": "16", "VV_TILE_LOG2W": "3"}]
 
 
 def case(seed):
@@ -61,8 +61,7 @@ def case(seed):
 
 def main():
     lo, hi = int(sys.argv[1]), int(sys.argv[2])
-    # FUZZ_X=1: the experimental build of the library (the VV_SWEEP / VV_SKEW entries of ENVS select kernels only it has; the product ignores them)
-    ctx = vv.Context(0, lib_path=vv.LIB_X_PATH) if os.environ.get("FUZZ_X") == "1" else vv.Context(0)
+    ctx = vv.Context(0)
     bad = 0
     only = os.environ.get("FUZZ_ENV_ONLY")          # index into ENVS: run only the seeds that use that entry
     for seed in range(lo, hi):

@@ -28,8 +28,7 @@ import torch
 import volviz_amd as vv
 
 # (every name here is read by vv_knobs::read(); a variant that sets another VV_* name is refused below)
-KNOBS = ("VV_XCD_BAND", "VV_LDS_RESERVE", "VV_UNROLL", "VV_TILE_LOG2W", "VV_SWEEP", "VV_SKEW",
-         "VV_SWEEP_WX", "VV_SWEEP_WY", "VV_SWEEP_AHEAD", "VV_SWEEP_STEPS", "VV_LDS_RESERVE_PHONG", "VV_BRICKED", "VV_ZPAIR", "VV_BLOCK_W", "VV_TAIL", "VV_PHONG2", "VV_PHONG_PAIR", "VV_ZFAST")
+KNOBS = ("VV_XCD_BAND", "VV_LDS_RESERVE", "VV_UNROLL", "VV_TILE_LOG2W", "VV_LDS_RESERVE_PHONG", "VV_BRICKED", "VV_ZPAIR", "VV_BLOCK_W", "VV_TAIL", "VV_ZFAST", "VV_FORCE_BIG")
 
 # name, env, slab_rows (None = whole frame), extra
 VARIANTS = [
@@ -70,8 +69,6 @@ def main():
         unknown = [k for k in env if k.startswith("VV_") and k not in KNOBS]
         if unknown:
             sys.exit(f"variant {name!r} sets {unknown}: not a knob the library reads (it would silently measure the default)")
-    if any(k in env for _, env, _ in variants for k in ("VV_SWEEP", "VV_SKEW", "VV_PHONG2")):
-        vv.LIB_PATH = vv.LIB_X_PATH          # the opt-in kernels live in the experimental build of the library
     import bench
     n, W, H, steps = args.size, 1920, 1080, 512
     dev = torch.device("cuda", 0)

@@ -8,6 +8,5 @@ VARIANTS = [
     ("64x4, unroll 2", {"VV_BLOCK_W": "64", "VV_UNROLL": "2"}, None),
     ("64x4, xcd_band 2", {"VV_BLOCK_W": "64", "VV_XCD_BAND": "2"}, None),
     ("128x2, xcd_band 4", {"VV_BLOCK_W": "128", "VV_XCD_BAND": "4"}, None),
-    ("64x4 + skew", {"VV_BLOCK_W": "64", "VV_SKEW": "3"}, None),
     ("32x8 again", {}, None),
 ]

@@ -12,6 +12,5 @@ VARIANTS = [
     ("xcd_band 2", {"VV_XCD_BAND": "2"}, None),
     ("xcd_band 0", {"VV_XCD_BAND": "0"}, None),
     ("rows 34-43 (one round)", {}, (34, 43)),
-    ("skew (bricked)", {"VV_SKEW": "3"}, None),
     ("linear layout", {"VV_BRICKED": "0"}, None),
 ]

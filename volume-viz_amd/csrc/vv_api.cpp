@@ -22,19 +22,16 @@ using namespace vv;
 // volume load -- never on the per-frame path.
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
-    int bricked = -1, zpair = -1, zfast = -1, sweep = -1, sweep_trace = 0, force_big = 0;
-    int skew = -1, block_w = -1, tail = -1, phong2 = -1, phong_pair = -1;
-    int sw_wx = -1, sw_wy = -1, sw_ahead = -1, sw_steps = -1, sw_blocks = -1, sw_verbose = 0;
+    int bricked = -1, zpair = -1, zfast = -1, force_big = 0;
+    int block_w = -1, tail = -1;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
     {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
-        skew = geti("VV_SKEW", -1); block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1); phong2 = geti("VV_PHONG2", -1); phong_pair = geti("VV_PHONG_PAIR", -1);
-        sw_wx = geti("VV_SWEEP_WX", -1); sw_wy = geti("VV_SWEEP_WY", -1); sw_ahead = geti("VV_SWEEP_AHEAD", -1); sw_steps = geti("VV_SWEEP_STEPS", -1); sw_blocks = geti("VV_SWEEP_BLOCKS", -1);
-        sw_verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
-        sweep = geti("VV_SWEEP", -1); zfast = geti("VV_ZFAST", -1); sweep_trace = getenv("VV_SWEEP_TRACE") != nullptr; force_big = getenv("VV_FORCE_BIG") != nullptr;
+        block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1);
+        zfast = geti("VV_ZFAST", -1); force_big = getenv("VV_FORCE_BIG") != nullptr;
     }
 };
 
@@ -68,8 +65,7 @@ struct vv_context {
     std::vector<uint8_t> row_buf;
     int last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // vv_debug_last_launch
     unsigned long long *d_counter = nullptr;
-    unsigned long long *d_trace = nullptr; int trace_blocks = 0;      // developer trace of the sweep kernel (VV_SWEEP_TRACE=1)
-    bool counter_valid = false, sweep_err_valid = false;   // counters of the last instrumented frame / word 7 of the last sweep frame
+    bool counter_valid = false;          // counters of the last instrumented frame
     // streamed upload
     hipStream_t copy_stream = nullptr, promo_stream = nullptr;   // H2D copies / u8 -> f32 promotion kernels
     void *pin[2] = {nullptr, nullptr}; hipEvent_t pin_ev[2] = {nullptr, nullptr}; int pin_next = 0;   // pin_ev[b]: staging buffers b free again
@@ -218,7 +214,6 @@ int vv_shutdown(vv_context *c)
     if (c->d_slice) hipFree(c->d_slice);
     if (c->d_gen) hipFree(c->d_gen);
     if (c->d_counter) hipFree(c->d_counter);
-    if (c->d_trace) hipFree(c->d_trace);
     for (int i = 0; i < 2; ++i) {
         if (c->pin[i]) hipHostFree(c->pin[i]);
         if (c->pin_ev[i]) hipEventDestroy(c->pin_ev[i]);
@@ -268,7 +263,7 @@ static int install_volume(vv_context *c, const void *src, bool src_on_device, in
     c->knobs.read();
     // one slice + one row + 16 bytes of zero padding: weight-0 corner fetches of edge
     // samples land here instead of needing index clamps (see vv_device.h VolumeView)
-    const size_t pad = (size_t)nx * ny * vsz + 2 * (size_t)nx * vsz + 4096;   // (the sweep's loaders read whole 128-byte cells: up to one more row + a cell)
+    const size_t pad = (size_t)nx * ny * vsz + 2 * (size_t)nx * vsz + 4096;
     drop_bricks(c);
     if (c->d_vol) { HIPCHK(c, hipFree(c->d_vol)); c->d_vol = nullptr; }   // the reference leaks here
     HIPCHK(c, hipMalloc(&c->d_vol, bytes + pad));
@@ -317,70 +312,11 @@ int vv_prepare_layouts(vv_context *c, int which, void *stream)
     return built;
 }
 
-// The sweep planner on its own (host arithmetic only: no device is touched), for tests and for callers that want to know
-// whether a frame would qualify: out = {enabled, major, sgn, wx, wy, pxc, ry, group, ring, ntx, nty, nl}.
-int vv_debug_plan_sweep(int W, int H, const camera_params *cam, const vv_ray_source *rays, const float step[3],
-                        int voxel_type, int nx, int ny, int nz, int phong, int slice_type, int out[12])
-{
-#ifndef VV_EXPERIMENTAL
-    (void)W; (void)H; (void)cam; (void)rays; (void)step; (void)voxel_type; (void)nx; (void)ny; (void)nz; (void)phong; (void)slice_type; (void)out;
-    return fail(nullptr, VV_ERR_INVALID, "vv_debug_plan_sweep: the sweep kernel is only part of the experimental build (libvolviz_hip_x.so)");
-#else
-    if (!cam || !rays || !step || !out || W < 1 || H < 1 || nx < 1 || ny < 1 || nz < 1) return VV_ERR_INVALID;
-    MarchArgs A;
-    memset(&A, 0, sizeof A);
-    FrameParams &P = A.P;
-    P.W = W; P.H = H;
-    P.nbx = W / kSlab + ((W % kSlab) ? 1 : 0); P.nby = H / kSlab + ((H % kSlab) ? 1 : 0);
-    P.rb = 0; P.re = P.nby; P.band = 4; P.count = 1; P.index = 0;
-    P.alpha_unit = 1;                 // (the planner's answer for a table with opacities in [0, 1])
-    P.slice_type = slice_type;
-    for (int a = 0; a < 3; ++a) {
-        if (!(cam->scale[a] > 0.f)) return VV_ERR_INVALID;
-        P.cam_pos[a] = cam->origin[a]; P.scale[a] = cam->scale[a]; P.inv_scale[a] = 1.0f / cam->scale[a]; P.step[a] = step[a];
-    }
-    P.ray_mode = rays->mode; P.quantize8 = rays->quantize8;
-    if (rays->mode == VV_RAYS_ANALYTIC) { int rc = camera_basis(nullptr, P, cam, rays, W, H); if (rc) return rc; }
-    const uint32_t vsz = voxel_type == VV_VOXEL_F32 ? 4u : 1u;
-    A.V.data = (const void *)(uintptr_t)256; A.V.nx = nx; A.V.ny = ny; A.V.nz = nz;
-    A.V.row_bytes = (uint32_t)nx * vsz; A.V.slice_bytes = A.V.row_bytes * (uint32_t)ny;
-    A.V_type = voxel_type; A.phong = phong != 0;
-    A.sweep.wx = A.sweep.wy = A.sweep.ahead = A.sweep.steps = A.sweep.blocks = -1;
-    A.sweep.verbose = getenv("VV_SWEEP_VERBOSE") != nullptr;
-    const int last_written = H >= 2 ? H - 2 : 0;
-    plan_sweep(A, 0, ((last_written + 1 + 7) / 8) * 8, 0);
-    const SweepArgs &S = A.sweep;
-    const int v[12] = {S.enabled, S.major, S.sgn, S.wx, S.wy, S.pxc, S.ry, S.group, S.ring, S.ntx, S.nty, S.nl};
-    memcpy(out, v, sizeof v);
-    return VV_OK;
-#endif
-}
-
-// 1 in the experimental build (libvolviz_hip_x.so: march_skew_kernel, sweep_kernel and march_phong2_kernel behind VV_SKEW / VV_SWEEP / VV_PHONG2), 0 in the product
-int vv_build_is_experimental(void)
-{
-#ifdef VV_EXPERIMENTAL
-    return 1;
-#else
-    return 0;
-#endif
-}
-
 int vv_reread_env(vv_context *c)
 {
     if (!c) return VV_ERR_INVALID;
     c->knobs.read();
     return VV_OK;
-}
-
-int vv_debug_sweep_trace(vv_context *c, unsigned long long *out, int max_blocks)
-{
-    if (!c || !out || !c->d_trace || max_blocks < 0) return VV_ERR_INVALID;
-    const int n = c->trace_blocks < max_blocks ? c->trace_blocks : max_blocks;
-    if (hipSetDevice(c->device) != hipSuccess) return VV_ERR_DEVICE;
-    if (c->timed && hipEventSynchronize(c->ev1) != hipSuccess) return VV_ERR_DEVICE;      // the frame that wrote the trace
-    if (hipMemcpy(out, c->d_trace, 64ull * n, hipMemcpyDeviceToHost) != hipSuccess) return VV_ERR_DEVICE;
-    return n;
 }
 
 int vv_device_bytes(const vv_context *c, unsigned long long out[4])
@@ -395,7 +331,7 @@ int vv_device_bytes(const vv_context *c, unsigned long long out[4])
 
 int vv_debug_counters(vv_context *c, unsigned long long out[16])
 {
-    if (!c || !out || (!c->counter_valid && !c->sweep_err_valid)) return VV_ERR_INVALID;
+    if (!c || !out || !c->counter_valid) return VV_ERR_INVALID;
     if (hipEventSynchronize(c->ev1) != hipSuccess) return VV_ERR_DEVICE;
     if (hipMemcpy(out, c->d_counter, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return VV_ERR_DEVICE;
     return VV_OK;
@@ -778,7 +714,6 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     P.step[0] = 1.f / (float)c->nx; P.step[1] = 1.f / (float)c->ny; P.step[2] = 1.f / (float)c->nz;   // :415
     P.ert_thr = .95f; P.ert_true = 0; P.alpha_unit = c->tf_alpha_unit;
     A.tex8 = true; A.instr = false;
-    A.bricks = nullptr;
     if (opts) {
         if (opts->step[0] > 0.f || opts->step[1] > 0.f || opts->step[2] > 0.f) {
             P.step[0] = opts->step[0]; P.step[1] = opts->step[1]; P.step[2] = opts->step[2];
@@ -788,8 +723,9 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         A.tex8 = opts->filter != VV_FILTER_EXACT;
         if (!(opts->slab_row_begin == 0 && opts->slab_row_end == 0)) { rb = opts->slab_row_begin; re = opts->slab_row_end; }
         if (opts->shard_count > 1) { s_count = opts->shard_count; s_index = opts->shard_index; s_band = opts->shard_band; }
-        A.instr = opts->count_samples != 0 || opts->touched_bricks != nullptr;
-        A.bricks = opts->touched_bricks;
+        A.instr = opts->count_samples != 0 || opts->touched_bricks != nullptr || opts->touched_lines != nullptr;
+        A.I.bricks = opts->touched_bricks;
+        A.I.lines = opts->touched_lines; A.I.line_bits = opts->touched_lines ? opts->touched_line_bits : 0; A.I.lines_all = opts->touched_lines_all;
     }
     float min_step = INFINITY;
     for (int a = 0; a < 3; ++a) {
@@ -949,16 +885,6 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     A.unroll = (A.strips.tile_log2w == 5 || beyond_caches) ? 3 : 2;
     // (re-swept with tools/ab_reserve.sh at the end of round 1: 4 blocks per CU for volumes up to 1 GiB)
     A.lds_reserve = !beyond_caches ? 36000 : (A.strips.tile_log2w == 5 ? big_reserve : 155000);
-    // Skewed lock step (march_skew_kernel, speed only): lanes of a wave aligned along the axis the rays march along (y or
-    // z, whichever the central ray crosses more steeply in voxels per sample).  VV_SKEW=0/1/2 overrides (1 / 2: the axis).
-    A.strips.skew_axis = 0;
-#ifdef VV_EXPERIMENTAL
-    if (rays->mode == VV_RAYS_ANALYTIC && !shading->phongShading) {
-        const float sy = fabsf(P.look[1] * P.step[1] * P.inv_scale[1] * (float)c->ny), sz = fabsf(P.look[2] * P.step[2] * P.inv_scale[2] * (float)c->nz);
-        const int ax = sz >= sy ? 2 : 1;
-        if (K.skew > 0) A.strips.skew_axis = K.skew <= 2 ? K.skew : ax;
-    }
-#endif
     // Block shape (speed only).  32 x 2 wave tiles: stacked (32 x 8 pixels), 2 x 2 (64 x 4) or side by side (128 x 2): the partial lines two x-adjacent wave
     // tiles share are then fetched within one block; strips get lower.  8 x 8 wave tiles: side by side (32 x 8), 2 x 2 (16 x 16) or stacked (8 x 32).  VV_BLOCK_W=8...128.
     //   measured (tools/ab_env.sh, profiles/r03_block_shape.txt): 64 x 4: C3 -2.4 % (EA bytes 1.474 -> 1.364 x algorithmic), u8 1024^3 -1.3 %, tilted views -1.7 %, but
@@ -967,7 +893,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     //   C1 -6.5 %, other orbits -2 ... -4 %, 512^3 and the 3840 x 2160 frame -0.5 %: used for every frame with 8 x 8 tiles.
     A.strips.blk_log2w = 5;
     A.strips.tail_batch = K.tail == 0 ? 0 : 1;
-    const int rows_px_8 = A.strips.n_strips * 8;              // (the sweep planner's view of the shard: strips of 8 rows)
+    const int rows_px_8 = A.strips.n_strips * 8;              // (the shard's pixel rows as strips of 8)
     int block_w = A.strips.tile_log2w == 3 ? 16 : ((A.strips.tile_log2w == 5 && c->vol_bytes >= (1ull << 30) && density > 3.5f) ? 64 : 32);      // (>=: u8 1024^3 -2 %, tools/policy_sweep.sh)
     if (K.block_w >= 8 && K.block_w <= 128 && (K.block_w & (K.block_w - 1)) == 0) block_w = K.block_w;
     {
@@ -1027,8 +953,6 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     // bricked copy likes 5: rotated C3 + Phong 2.25 -> 2.13 ms; C5 5.95 ms with 2, 6.25 with 3, 6.55 with 5)
     A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f && !use_bricks) ? 30000 : 13000);
     if (K.lds_reserve_phong >= 0 && K.lds_reserve_phong <= 146 * 1024) A.lds_reserve_phong = K.lds_reserve_phong;
-    A.phong_pair = K.phong_pair > 0 ? 1 : 0;            // (VV_PHONG_PAIR=1, experimental builds: march_phong_pair_kernel)
-    A.phong_v2 = K.phong2 > 0 ? K.phong2 : 0;           // 0: march_phong_kernel; 1 / 2 (VV_PHONG2, experimental builds): march_phong2_kernel with one / two slabs per block
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
     int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));
@@ -1052,7 +976,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (((uintptr_t)d_out & 3) != 0) return fail(c, VV_ERR_INVALID, "vv_render: output buffer must be 4-byte aligned");
 
     if (A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), st));
-    c->counter_valid = A.instr; c->sweep_err_valid = false;
+    c->counter_valid = A.instr;
     {
         const int layout = A.xpair ? 5 : A.V.zfast ? 4 : (A.V.bricks ? 2 : (A.V.zpair ? 3 : ((A.V.big || (A.phong && beyond_caches)) ? 1 : 0)));
         const int v[8] = {A.strips.tile_log2w, A.strips.blk_log2w, A.unroll, A.phong ? A.lds_reserve_phong : A.lds_reserve, layout, have_basis ? 1 : 0,
@@ -1060,39 +984,13 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         memcpy(c->last_launch, v, sizeof v);
     }
     HIPCHK(c, hipEventRecord(c->ev0, st));
-    bool sweep_frame = false;
     if (A.phong) {
         // (linear volumes beyond the caches take the 64-bit-addressing build even below 4 GiB: the other one is compiled for 5 waves per SIMD, which only
         //  cache-resident volumes want -- 1000^3 f32: 1.884 -> 1.817 ms, tools/ab_env.sh VV_FORCE_BIG=1)
         if (A.xpair) launch_raymarch_xpair(A, st); else if (A.V.zfast) launch_raymarch_zfast(A, st); else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); } else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big || beyond_caches) launch_raymarch_big(A, st); else launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
         if (W >= 2 && H >= 2) launch_rad(A, st);
-        bool sweep = false;
-#ifdef VV_EXPERIMENTAL
-        // Slab sweep (vv_sweep.hip): the volume streamed through an LDS slice ring (opt-in: VV_SWEEP=1, profiles/EXPERIMENTS.md).
-        if (K.sweep >= 0) sweep = K.sweep != 0;
-        if (sweep) {
-            const int own_bands = s_count > 1 ? A.strips.n_strips / A.strips.strips_per_band : 0;          // (the ratio does not depend on the strip height)
-            A.sweep.wx = K.sw_wx; A.sweep.wy = K.sw_wy; A.sweep.ahead = K.sw_ahead; A.sweep.steps = K.sw_steps; A.sweep.blocks = K.sw_blocks;
-            A.sweep.verbose = K.sw_verbose;
-            plan_sweep(A, A.strips.y0, rows_px_8, own_bands);
-            sweep = A.sweep.enabled != 0;
-        }
-        if (sweep && K.sweep_trace) {
-            const int nb = ((A.sweep.nty + 7) / 8) * 8 * A.sweep.ntx;
-            if (!c->d_trace) { if (hipMalloc((void **)&c->d_trace, 8ull * 8 * 65536) != hipSuccess) c->d_trace = nullptr; }
-            if (c->d_trace && nb <= 65536) { HIPCHK(c, hipMemsetAsync(c->d_trace, 0, 64ull * nb, st)); A.sweep.trace = c->d_trace; c->trace_blocks = nb; }
-        }
-        if (sweep) {
-            // the kernel reports a clamped footprint / a block that could not be served in counter[7] of EVERY frame, instrumented or not
-            if (!A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter + 7, 0, sizeof(unsigned long long), st));
-            // (false: the kernel's LDS no longer fits a CU, or its attributes could not be set: the gather kernel takes the frame)
-            if (launch_raymarch_sweep(A, st)) { sweep_frame = true; c->sweep_err_valid = true; }
-            else sweep = false;
-        }
-#endif
-        if (sweep) { }
-        else if (A.xpair) launch_raymarch_xpair(A, st);
+        if (A.xpair) launch_raymarch_xpair(A, st);
         else if (A.V.zfast) launch_raymarch_zfast(A, st);
         else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); }
         else if (A.V.zpair) launch_raymarch_zpair(A, st);
@@ -1108,13 +1006,6 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         HIPCHK(c, hipStreamSynchronize(st));
     } else if (!stream) {
         HIPCHK(c, hipStreamSynchronize(st));
-    }
-    if (sweep_frame && (!out_on_device || !stream)) {
-        // synchronous call: the frame is complete, so its error word can be looked at (an enqueue-only call cannot; such callers read
-        // vv_debug_counters()[7] after synchronising: bits 0..47 must be zero, bits 48+ count blocks that finished on gathers)
-        unsigned long long e = 0;
-        HIPCHK(c, hipMemcpy(&e, c->d_counter + 7, sizeof e, hipMemcpyDeviceToHost));
-        if (e & 0xFFFFFFFFFFFFull) return fail(c, VV_ERR_DEVICE, "vv_render: the sweep kernel flagged an error (a slice image larger than planned): the frame is not trustworthy; unset VV_SWEEP");
     }
     return VV_OK;
 }

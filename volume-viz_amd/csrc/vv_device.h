@@ -75,7 +75,7 @@ template <int VOXEL> struct BrickGeom;
 #endif
 template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t xlog2 = VV_BRICK_XLOG2, bx = 1u << xlog2, halo = VV_BRICK_HALO, row = (bx + halo) * 4,
                                              zlog2 = VV_BRICK_ZLOG2, bz = 1u << zlog2, rows = 4 * bz, brick = rows * row; };
-template <> struct BrickGeom<VV_VOXEL_U8>  { static constexpr uint32_t xlog2 = 2, bx = 4, row = 8, zlog2 = 2, bz = 4, rows = 16, brick = 128; };
+template <> struct BrickGeom<VV_VOXEL_U8>  { static constexpr uint32_t xlog2 = 2, bx = 4, halo = 1, row = 8, zlog2 = 2, bz = 4, rows = 16, brick = 128; };
 enum { LAYOUT_LINEAR = 0, LAYOUT_LINEAR_BIG = 1, LAYOUT_BRICKED = 2, LAYOUT_ZPAIR = 3, LAYOUT_ZFAST = 4 };
 
 // Everything a frame needs that is uniform over the launch.
@@ -565,6 +565,38 @@ __device__ __forceinline__ uint32_t pack_rgba(float r, float g, float b, float a
     uint32_t B = (uint32_t)(fmaxf(0.f, fminf(b, 1.f)) * 255.0f);
     uint32_t A = (uint32_t)(fmaxf(0.f, fminf(a, 1.f)) * 255.0f);
     return R | (G << 8) | (B << 16) | (A << 24);
+}
+
+// Instrumentation of a (never timed) frame: what the roofline's byte model is counted from.
+struct InstrArgs {
+    uint32_t *bricks;        // 1 bit per 8^3-voxel brick of the volume touched by an executed in-volume sample (SURVEY 8d's algorithmic bytes), or NULL
+    uint32_t *lines;         // 1 bit per 128-byte line of the layout this frame SAMPLES (offsets from the layout's base), or NULL
+    uint64_t  line_bits;     // size of `lines` in bits (lines beyond it are not marked)
+    int       lines_all;     // 0: lines of executed in-volume samples only (what has to be fetched at line granularity);
+                             // 1: lines of every gather the kernel issues, idle lanes and out-of-volume samples included
+};
+__device__ __forceinline__ void mark_line_range(const InstrArgs &I, uint64_t off, uint32_t bytes)
+{
+    for (uint64_t l = off >> 7; l <= (off + bytes - 1u) >> 7; ++l) {
+        if (l >= I.line_bits) continue;
+        const uint32_t bit = 1u << (l & 31);
+        if (!(I.lines[l >> 5] & bit)) atomicOr(&I.lines[l >> 5], bit);
+    }
+}
+
+// byte offsets (from VolumeView::bricks) of the four row loads fetch_corners() issues on the bricked copy (instrumentation only)
+template <int VOXEL>
+__device__ __forceinline__ void brick_offsets(const VolumeView &V, uint32_t ix, uint32_t iy, uint32_t iz, uint64_t a[4])
+{
+    using G = BrickGeom<VOXEL>;
+    const uint32_t ya = iy & 3u, za = iz & (G::bz - 1u);
+    const uint32_t oy0 = (iy >> 2) * V.b_sy + ya * G::row;
+    const uint32_t oy1 = oy0 + (ya == 3u ? V.b_sy - 3u * G::row : G::row);
+    const uint64_t m0 = (uint64_t)(iz >> G::zlog2) * V.b_sz64, m1 = m0 + (za == G::bz - 1u ? V.b_sz64 : 0u);
+    const uint32_t zi0 = za * 4u * G::row, zi1 = za == G::bz - 1u ? 0u : zi0 + 4u * G::row;
+    const uint32_t ox = VOXEL == VV_VOXEL_F32 ? (ix >> G::xlog2) * G::brick + ((ix & (G::bx - 1u)) << 2) : (ix >> 2) * G::brick;
+    a[0] = (m0 << 6) + ox + oy0 + zi0; a[1] = (m0 << 6) + ox + oy1 + zi0;
+    a[2] = (m1 << 6) + ox + oy0 + zi1; a[3] = (m1 << 6) + ox + oy1 + zi1;
 }
 
 __device__ __forceinline__ void mark_bricks(uint32_t *bm, const VolumeView &V, float px, float py, float pz)

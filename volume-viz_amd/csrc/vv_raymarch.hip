@@ -67,6 +67,47 @@ __device__ __forceinline__ void fetch_any(const VolumeView &V, float px, float p
 #endif
 }
 
+// Instrumented frames only: the 128-byte lines (offsets from the sampled layout's base) the gathers of one sample touch -- the address
+// arithmetic of fetch_any() for this translation unit's layout, restated (InstrArgs::lines).
+template <int VOXEL, bool TEX8>
+__device__ __noinline__ void mark_sample_lines(const InstrArgs &I, const VolumeView &V, float px, float py, float pz)
+{
+    uint32_t ix, iy, iz;
+    (void)axis_coord<TEX8>(px, (float)V.nx, (float)(V.nx - 1), ix);
+    (void)axis_coord<TEX8>(py, (float)V.ny, (float)(V.ny - 1), iy);
+    (void)axis_coord<TEX8>(pz, (float)V.nz, (float)(V.nz - 1), iz);
+    constexpr bool F = VOXEL == VV_VOXEL_F32;
+#if defined(VV_ZPAIR)
+    const uint32_t rec = F ? 8u : 2u, bytes = F ? 16u : 4u;
+#ifdef VV_XPAIR
+    const uint64_t off = (uint64_t)ix * V.zp_slab_bytes + (uint64_t)iy * V.zp_row_bytes + (uint64_t)iz * rec;
+#else
+    const uint64_t off = (uint64_t)iz * V.zp_slab_bytes + (uint64_t)iy * V.zp_row_bytes + (uint64_t)ix * rec;
+#endif
+    mark_line_range(I, off, bytes); mark_line_range(I, off + V.zp_row_bytes, bytes);
+#else
+    if constexpr (kLayout == LAYOUT_LINEAR || kLayout == LAYOUT_LINEAR_BIG) {
+        const uint64_t o = (uint64_t)iz * V.slice_bytes + (uint64_t)iy * V.row_bytes + (F ? ix * 4u : (ix & ~3u));
+        mark_line_range(I, o, 8); mark_line_range(I, o + V.row_bytes, 8);
+        mark_line_range(I, o + V.slice_bytes, 8); mark_line_range(I, o + V.slice_bytes + V.row_bytes, 8);
+    } else if constexpr (kLayout == LAYOUT_ZFAST) {
+        const uint64_t o = (uint64_t)ix * V.zf_slice_bytes + (uint64_t)iy * V.zf_row_bytes + (F ? iz * 4u : (iz & ~3u));
+        mark_line_range(I, o, 8); mark_line_range(I, o + V.zf_row_bytes, 8);
+        mark_line_range(I, o + V.zf_slice_bytes, 8); mark_line_range(I, o + V.zf_slice_bytes + V.zf_row_bytes, 8);
+    } else {
+        using G = BrickGeom<VOXEL>;
+        uint64_t a[4];
+        brick_offsets<VOXEL>(V, ix, iy, iz, a);
+        if constexpr (F && G::halo == 0) {
+            const uint32_t dx = (ix & (G::bx - 1u)) == G::bx - 1u ? G::brick - (G::bx - 1u) * 4u : 4u;
+            for (int k = 0; k < 4; ++k) { mark_line_range(I, a[k], 4); mark_line_range(I, a[k] + dx, 4); }
+        } else {
+            for (int k = 0; k < 4; ++k) mark_line_range(I, a[k], 8);
+        }
+    }
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // rad pre-pass (blockMin, kernel.cu:80-97,329): one wave per slab, four (clamped) footprint
 // pixels per lane, minimum by wave shuffles -- no LDS, no block barrier.  The minimum of a set of
@@ -134,7 +175,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                                                     const float *__restrict__ rad,
                                                     uint32_t *__restrict__ pixels,
                                                     unsigned long long *__restrict__ counter,
-                                                    uint32_t *__restrict__ bricks, StripMap M)
+                                                    InstrArgs I, StripMap M)
 {
     __shared__ float lds_tf[1024];
 
@@ -258,10 +299,12 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                     if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
                 }
                 if (INSTR) {
+                    const bool inv = bounds_check(tx[u], ty[u], tz[u]);
                     if (live) {
                         executed++;
-                        if (bricks && bounds_check(tx[u], ty[u], tz[u])) mark_bricks(bricks, V, tx[u], ty[u], tz[u]);
+                        if (I.bricks && inv) mark_bricks(I.bricks, V, tx[u], ty[u], tz[u]);
                     }
+                    if (I.lines && (I.lines_all || (live && inv))) mark_sample_lines<VOXEL, TEX8>(I, V, tx[u], ty[u], tz[u]);
                 }
                 {
 #pragma clang fp contract(off)
@@ -318,10 +361,12 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                     if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
                 }
                 if (INSTR) {
+                    const bool inv = bounds_check(tx[u], ty[u], tz[u]);
                     if (live) {
                         executed++;
-                        if (bricks && bounds_check(tx[u], ty[u], tz[u])) mark_bricks(bricks, V, tx[u], ty[u], tz[u]);
+                        if (I.bricks && inv) mark_bricks(I.bricks, V, tx[u], ty[u], tz[u]);
                     }
+                    if (I.lines && (I.lines_all || (live && inv))) mark_sample_lines<VOXEL, TEX8>(I, V, tx[u], ty[u], tz[u]);
                 }
                 {
                     // :268-270 + blend :107-118, predicated: with bf == 0 the sums are unchanged
@@ -356,214 +401,6 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         if (kLayout == LAYOUT_ZPAIR && lane == 0 && executed) atomicAdd(counter + 3, 1ull);     // ... the z-pair copy
     }
 }
-
-#ifdef VV_EXPERIMENTAL
-// ---------------------------------------------------------------------------
-// march_skew_kernel: march_kernel with a per-lane sample offset ("skewed lock step").
-//
-// The reference's sample shells are spheres about a point that is not the eye (DESIGN.md pin 1), so the lanes of a
-// wave at the SAME sample index sit on different volume slices (C3: 3 slices apart in the median 32 x 2 wave, 6 at the
-// 90th percentile, more where a tile straddles the cube's silhouette).  A wave therefore keeps several slices' worth of
-// cache lines live per gather, and the L2 (4 MiB per XCD, shared by 64 such blocks) turns over before neighbouring
-// lanes and waves have used them (profiles/r03_traffic_split.txt).  Here lane L takes sample s = t - o_L at wave step t,
-// o_L = round((c_L - c_ref) / dc_L) with c the lane's first sample position along the march axis in voxels: the wave's
-// samples of one step lie within about one sample spacing of a common slice.  Every lane executes exactly the
-// reference's sequence of operations for its ray (chunks of 30, running position sums, the ERT rule); only WHEN a lane
-// does them changes, so frames and sample counts stay bit-identical for any offsets.
-// ---------------------------------------------------------------------------
-constexpr int kSkewMax = 30;
-template <int SLICE, int VOXEL, bool TEX8, bool GRAY, bool INSTR, int U>
-__global__ __launch_bounds__(256) void march_skew_kernel(FrameParams P, VolumeView V,
-                                                         const float4 *__restrict__ tf,
-                                                         const float *__restrict__ rad,
-                                                         uint32_t *__restrict__ pixels,
-                                                         unsigned long long *__restrict__ counter,
-                                                         uint32_t *__restrict__ bricks, StripMap M)
-{
-    __shared__ float lds_tf[1024];
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bl = M.blk_log2w, ntx = (P.W + (1 << bl) - 1) >> bl;        // block = 2^bl x (256 >> bl) pixels
-    int strip, tile_x;
-    if (M.xcd_band > 0) {
-        const int L = blockIdx.x, per_band = ntx * M.xcd_band;
-        const int xcd = L & 7, j = L >> 3;
-        const int band = (j / per_band) * 8 + xcd, w = j % per_band;
-        strip = band * M.xcd_band + w / ntx; tile_x = w % ntx;
-    } else { strip = blockIdx.x / ntx; tile_x = blockIdx.x % ntx; }
-    const int tw = M.tile_log2w, th = 6 - tw;
-    const int wx = wave & (((1 << bl) >> tw) - 1), wy = wave >> (bl - tw);
-    const int x = (tile_x << bl) + (wx << tw) + (lane & ((1 << tw) - 1));
-    const int y = M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * (256 >> bl) + (wy << th) + (lane >> tw);
-    if (strip >= M.n_strips) return;                       // block-uniform, before any barrier
-    stage_tf_planar(lds_tf, tf);
-    const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax = P.H >= 2 ? P.H - 2 : 0;
-    const bool in_frame = x <= xmax && y <= ymax && row_owned(P, y);
-
-    float res_r = 0.f, res_g = 0.f, res_b = 0.f, res_a = 0.f;
-    unsigned long long executed = 0, slots = 0;
-    bool write_zero = false;
-
-    Ray r;
-    bool alive = false;
-    if (in_frame) {
-        f3 front, back;
-        ray_endpoints(P, x, y, front, back);
-        float length = vlen3(back.x - front.x, back.y - front.y, back.z - front.z);
-        if (length < 0.001f) {
-            write_zero = true;                                       // kernel.cu:334-338
-        } else {
-            float rd;
-            if (P.W < 2 || P.H < 2) {
-                rd = vlen3(front.x - P.cam_pos[0], front.y - P.cam_pos[1], front.z - P.cam_pos[2]);
-            } else {
-                int ox = owner_slab(x, P.W, P.nbx, P.conflict_x), oy = owner_slab(y, P.H, P.nby, P.conflict_y);
-                rd = rad[oy * P.nbx + ox];
-            }
-            setup_ray(P, front, back, rd, r);
-            alive = !r.cut_return;
-        }
-    }
-    if (!alive) { r.upper = -1.f; r.dist0 = 0.f; r.sstep = 1.f; r.origin = mk3(0, 0, 0); r.dir = r.origin; r.sdir = r.origin; }
-
-    // ---- the lane's offset (speed only: any value gives the same pixels) ----
-    int o = 0;
-    {
-        const bool az = M.skew_axis == 2;
-        const float isc = az ? P.inv_scale[2] : P.inv_scale[1], nn = az ? (float)V.nz : (float)V.ny;
-        const float p1 = (az ? r.origin.z + r.dir.z * r.dist0 + r.sdir.z : r.origin.y + r.dir.y * r.dist0 + r.sdir.y);
-        const float c = __builtin_fmaf(p1 - 0.5f, isc, 0.5f) * nn;           // first sample, in voxels along the march axis
-        const float dc = (az ? r.sdir.z : r.sdir.y) * isc * nn;              // voxels per sample (signed)
-        const bool fwd = alive && dc > 0.f, bwd = alive && dc < 0.f;
-        float cref = 0.f;
-        bool ok = false;
-        if (__any(fwd) && !__any(bwd)) {
-            float m = fwd ? c : INFINITY;
-            for (int q = 32; q > 0; q >>= 1) m = fminf(m, __shfl_xor(m, q));
-            cref = m; ok = fwd;
-        } else if (__any(bwd) && !__any(fwd)) {
-            float m = bwd ? c : -INFINITY;
-            for (int q = 32; q > 0; q >>= 1) m = fmaxf(m, __shfl_xor(m, q));
-            cref = m; ok = bwd;
-        }
-        if (ok) {
-            const float q = rintf((c - cref) / dc);                          // >= 0 for both directions
-            o = q >= 0.f ? (q < (float)kSkewMax ? (int)q : kSkewMax) : 0;    // (NaN -> 0)
-        }
-    }
-
-    float dist = r.dist0;
-    bool ert = false, stop = false, active = alive, lastc = false;
-    int i = 31 - o;              // the lane's next sample index within its chunk; 31 = "open the next chunk now"
-    int n = 0, chunks = 0;       // samples of the open chunk (0: none open / ray finished), chunks opened so far
-    float px = 0.f, py = 0.f, pz = 0.f;
-    const f3 sp = mk3(P.slice_point[0], P.slice_point[1], P.slice_point[2]);
-    const f3 sn = mk3(P.slice_normal[0], P.slice_normal[1], P.slice_normal[2]);
-    const int tmax = P.max_chunks * 30 + kSkewMax + U;                       // wave-uniform bound: every wave exits
-
-    for (int t = 0; t < tmax; t += U) {
-        // a lane has samples left unless its ray never started, its last chunk ended short (kernel.cu:255-257: the next
-        // `while (dist < upper)` fails) or it terminated for good
-        const bool pending = active && !(lastc && i > n) && !(P.ert_true && ert);
-        if (!__any(pending)) break;
-        // No lane has a sample left in its open chunk (the wave's rays have all terminated early and composite one sample
-        // per chunk, pin 4; or lanes idle before their first chunk): jump to the first lane's next chunk boundary instead of
-        // stepping -- and gathering -- through the idle slots.  (Positions are recomputed at every boundary, :249.)
-        if (!__any(i <= n && !stop)) {
-            int d = pending ? 31 - i : 64;       // (finished lanes no longer open chunks: their i may run on)
-            for (int q = 32; q > 0; q >>= 1) d = min(d, __shfl_xor(d, q));
-            i += d;
-        }
-        if (INSTR) slots += (unsigned long long)U * 64ull;
-        float tx[U], ty[U], tz[U], du[SLICE == SLICE_PLANE ? U : 1];
-        int iu[U];
-        bool lv[U];
-        typename CornerSel<VOXEL>::type C[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            // ---- chunk boundary of this lane: close the old one (:277), open the next (:248-249) ----
-            if (__any(i == 31)) {
-                if (i == 31) {
-#pragma clang fp contract(off)
-                    if (chunks > 0) { dist += r.sstep * kChunkSteps; if (P.ert_true && ert) r.upper = -1.f; }
-                    i = 1; n = 0;
-                    if (active) {
-                        if (chunks >= P.max_chunks) active = false;
-                        else {
-                            n = chunk_count(dist, r.upper, r.sstep);
-                            lastc = n < 30;                                  // the `while (dist < upper)` after this chunk fails
-                            // pin 4 (speed only here: `stop` masks the same samples; `ert` may still miss a hit of this trip)
-                            if (ert && P.alpha_unit) n = min(n, 1);
-                            px = r.origin.x + r.dir.x * dist; py = r.origin.y + r.dir.y * dist; pz = r.origin.z + r.dir.z * dist;
-                            ++chunks;
-                            if (n == 0) active = false;                      // !(dist < upper), or the first sample already beyond it
-                        }
-                    }
-                }
-            }
-            px += r.sdir.x; py += r.sdir.y; pz += r.sdir.z;                  // :141
-            tx[u] = __builtin_fmaf(px - 0.5f, P.inv_scale[0], 0.5f);
-            ty[u] = __builtin_fmaf(py - 0.5f, P.inv_scale[1], 0.5f);
-            tz[u] = __builtin_fmaf(pz - 0.5f, P.inv_scale[2], 0.5f);
-            fetch_any<VOXEL, TEX8>(V, tx[u], ty[u], tz[u], C[u]);
-            if (SLICE == SLICE_PLANE) du[u] = dist;
-            iu[u] = i; lv[u] = i <= n;                                       // (n == 0 while the lane idles before its first chunk / after its last)
-            ++i;
-        }
-        __builtin_amdgcn_sched_barrier(0);           // all 4U gathers are issued before the first is consumed
-        uint32_t idx[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) idx[u] = classify_index<VOXEL>(C[u], tx[u], ty[u], tz[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            // `stop` is the inner loop's break (:272-274), one flag per chunk: it is cleared where a chunk's first sample is
-            // consumed, not where the chunk was opened (samples of the old chunk in this trip are consumed after that point).
-            // VV_ERT_TRUE: a terminated ray takes no further sample at all.
-            if (iu[u] == 1) stop = false;
-            const bool live = lv[u] && !stop && !(P.ert_true && ert);
-            float cr, cg, cb, ca;
-            ca = lds_tf[768 + idx[u]];
-            cr = lds_tf[idx[u]];
-            if (GRAY) { cg = cb = cr; }
-            else { cg = lds_tf[256 + idx[u]]; cb = lds_tf[512 + idx[u]]; }
-            if (SLICE == SLICE_PLANE) {                                              // :193-198
-#pragma clang fp contract(off)
-                float vd = (float)iu[u] * r.sstep + du[u];                           // :254 (the dist of this sample's chunk)
-                float vx = r.origin.x + r.dir.x * vd, vy = r.origin.y + r.dir.y * vd, vz = r.origin.z + r.dir.z * vd;
-                float d = fabsf(sn.x * (vx - sp.x) + sn.y * (vy - sp.y) + sn.z * (vz - sp.z));
-                if (d < .01f) cr = fmaxf(0.f, fminf(cr + (.01f - d) * 100.f, 1.f));
-            }
-            if (INSTR) {
-                if (live) {
-                    executed++;
-                    if (bricks && bounds_check(tx[u], ty[u], tz[u])) mark_bricks(bricks, V, tx[u], ty[u], tz[u]);
-                }
-            }
-            {
-#pragma clang fp contract(off)
-                const float bf = (live && ca > kEps) ? ca * (1.f - res_a) : 0.f;
-                res_r = res_r + cr * bf;
-                if (!GRAY) { res_g = res_g + cg * bf; res_b = res_b + cb * bf; }
-                res_a = res_a + bf;
-            }
-            const bool hit = live && res_a > P.ert_thr;                              // :272-274
-            stop = stop || hit;
-            ert = ert || hit;
-        }
-    }
-
-    if (in_frame) {
-        if (GRAY) { res_g = res_r; res_b = res_r; }
-        pixels[(size_t)y * P.W + x] = write_zero ? 0u : pack_rgba(res_r, res_g, res_b, res_a);
-    }
-    if (INSTR) {
-        for (int q = 32; q > 0; q >>= 1) executed += __shfl_down(executed, q);
-        if (lane == 0 && executed) atomicAdd(counter, executed);
-        if (lane == 0 && slots) atomicAdd(counter + 1, slots);
-    }
-}
-
-#endif   // VV_EXPERIMENTAL
 
 // x / d and sqrt(x), IEEE-exact, without their range handling.  The compiler's expansion of `/` and sqrtf is a fixed core (v_rcp + one
 // Newton step, quotient + two residual corrections; v_sqrt + a test of the two neighbouring floats) wrapped in v_div_scale x 2 + v_div_fixup
@@ -614,7 +451,7 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
                                                           const float4 *__restrict__ tf, SlabMap M,
                                                           uint32_t *__restrict__ pixels,
                                                           unsigned long long *__restrict__ counter,
-                                                          uint32_t *__restrict__ bricks)
+                                                          InstrArgs I)
 {
     __shared__ float4 lds_tf[256];
     __shared__ float red[256];
@@ -776,7 +613,12 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
                     for (int u = 0; u < PU; ++u) {
                         const int i = i0 + u;
                         cache[i][tid] = (uint8_t)classify_index<VOXEL>(C[u], tx_[u], ty_[u], tz_[u]);
-                        if (INSTR && bricks && mine && i >= 1 && i <= 30 && bounds_check(tx_[u], ty_[u], tz_[u])) mark_bricks(bricks, V, tx_[u], ty_[u], tz_[u]);
+                        if (INSTR) {
+                            // (entries 1..30 of a compositing ray are the samples it can execute; entries 0 / 31 and the apron threads' are gradient-only)
+                            const bool need = mine && i >= 1 && i <= 30 && bounds_check(tx_[u], ty_[u], tz_[u]);
+                            if (I.bricks && need) mark_bricks(I.bricks, V, tx_[u], ty_[u], tz_[u]);
+                            if (I.lines && (I.lines_all || need)) mark_sample_lines<VOXEL, TEX8>(I, V, tx_[u], ty_[u], tz_[u]);
+                        }
                     }
                 };
                 // the full depth keeps its compile-time trip count (the short form alone cost cache-resident volumes 5-13 %)
@@ -853,11 +695,6 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
     }
 }
 
-#ifdef VV_EXPERIMENTAL
-#include "vv_raymarch_phong_pair.h"  // march_phong_pair_kernel: two x-adjacent slabs per block (-20 % bytes, +17 % time)
-#include "vv_raymarch_phong2.h"      // march_phong2_kernel: the second form of the Phong march (profiles/r04_phong_forms.txt), never faster
-#endif
-
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -873,26 +710,12 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
     dim3 grid(nblocks);
     // a.lds_reserve bytes of (unused) dynamic LDS cap the number of resident blocks per CU:
     // fewer waves share the 32 KB L1, which this gather kernel needs more than latency hiding
-#ifdef VV_EXPERIMENTAL
-    if (a.strips.skew_axis) {
-        if (a.unroll == 3)
-            hipLaunchKernelGGL((march_skew_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 3>), grid, dim3(256), (size_t)a.lds_reserve, s,
-                               a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
-        else if (a.unroll == 1)
-            hipLaunchKernelGGL((march_skew_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 1>), grid, dim3(256), (size_t)a.lds_reserve, s,
-                               a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
-        else
-            hipLaunchKernelGGL((march_skew_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 2>), grid, dim3(256), (size_t)a.lds_reserve, s,
-                               a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
-        return;
-    }
-#endif
     if (a.unroll == 3)
         hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 3>), grid, dim3(256), (size_t)a.lds_reserve, s,
-                           a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
+                           a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.I, a.strips);
     else
         hipLaunchKernelGGL((march_kernel<SLICE, VOXEL, TEX8, GRAY, INSTR, 2>), grid, dim3(256), (size_t)a.lds_reserve, s,
-                           a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.bricks, a.strips);
+                           a.P, a.V, a.tf, a.rad, a.pixels, a.counter, a.I, a.strips);
 }
 template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 static void launch_phong(const MarchArgs &a, hipStream_t s)
@@ -900,29 +723,8 @@ static void launch_phong(const MarchArgs &a, hipStream_t s)
     const int rows = a.slabs.n_regular + 1;                   // grid rows, dealt to the 8 XCDs round-robin
     constexpr int BAND = VV_PHONG_BAND;
     dim3 grid((unsigned)(((rows + 8 * BAND - 1) / (8 * BAND)) * 8 * BAND * a.P.nbx));
-#ifdef VV_EXPERIMENTAL
-    if (a.phong_v2 && a.P.safe_div) {       // (frames whose shading divisions would need range handling stay with march_phong_kernel)
-        const int S = a.phong_v2 == 2 ? 2 : 1, nbxg = (a.P.nbx + S - 1) / S;
-        dim3 grid2((unsigned)(((rows + 7) / 8) * 8 * nbxg));
-        if (S == 2)
-            hipLaunchKernelGGL((march_phong2_kernel<SLICE, VOXEL, TEX8, INSTR, 2>), grid2, dim3(512), (size_t)a.lds_reserve_phong, s,
-                               a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
-        else
-            hipLaunchKernelGGL((march_phong2_kernel<SLICE, VOXEL, TEX8, INSTR, 1>), grid2, dim3(256), (size_t)a.lds_reserve_phong, s,
-                               a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
-        return;
-    }
-#endif
-#ifdef VV_EXPERIMENTAL
-    if (a.phong_pair) {                      // two x-adjacent slabs per block
-        dim3 gridp((unsigned)(((rows + 7) / 8) * 8 * ((a.P.nbx + 1) / 2)));
-        hipLaunchKernelGGL((march_phong_pair_kernel<SLICE, VOXEL, TEX8, INSTR>), gridp, dim3(256), (size_t)a.lds_reserve_phong, s,
-                           a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
-        return;
-    }
-#endif
     hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), (size_t)a.lds_reserve_phong, s,
-                       a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.bricks);
+                       a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.I);
 }
 
 template <int SLICE, int VOXEL, bool TEX8>

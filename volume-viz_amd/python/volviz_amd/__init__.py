@@ -19,8 +19,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.normpath(os.path.join(_HERE, "..", ".."))          # volume-viz_amd/
 REPO_ROOT = os.path.normpath(os.path.join(PKG_ROOT, ".."))
 LIB_PATH = os.environ.get("VV_LIB", os.path.join(PKG_ROOT, "lib", "libvolviz_hip.so"))
-# the same sources with -DVV_EXPERIMENTAL: adds the opt-in kernels behind VV_SKEW / VV_SWEEP / VV_PHONG2 (never faster; kept as pinned experiments)
-LIB_X_PATH = os.path.join(PKG_ROOT, "lib", "libvolviz_hip_x.so")
 
 # kernel.cuh:18-20
 SLICE_NONE, SLICE_PLANE, SLICE_PLANE_CUT = -1, 0, 1
@@ -68,7 +66,8 @@ class vv_render_options(C.Structure):
     _fields_ = [("step", C.c_float * 3), ("ert_threshold", C.c_float), ("filter", C.c_int),
                 ("ert_mode", C.c_int), ("slab_row_begin", C.c_int), ("slab_row_end", C.c_int),
                 ("shard_band", C.c_int), ("shard_count", C.c_int), ("shard_index", C.c_int),
-                ("count_samples", C.c_int), ("touched_bricks", C.c_void_p)]
+                ("count_samples", C.c_int), ("touched_bricks", C.c_void_p),
+                ("touched_lines", C.c_void_p), ("touched_line_bits", C.c_ulonglong), ("touched_lines_all", C.c_int)]
 
 
 EXPORTS = [
@@ -80,9 +79,9 @@ EXPORTS = [
     "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid", "vv_debug_counters",
     "vv_first_pass", "vv_cut_plane_canonical", "vv_cut_plane_to_slice_params", "vv_slice_to_bgra",
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
-    "vv_prepare_layouts", "vv_device_bytes", "vv_debug_sweep_trace", "vv_reread_env", "vv_debug_plan_sweep",
+    "vv_prepare_layouts", "vv_device_bytes", "vv_reread_env",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
-    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset", "vv_debug_last_launch", "vv_build_is_experimental",
+    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset", "vv_debug_last_launch",
 ]
 
 _lib = None
@@ -143,9 +142,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_cut_plane_drag.argtypes = [vp, vp, vp, i, i, i, i]
     lib.vv_debug_counters.argtypes = [vp, vp]
     lib.vv_debug_last_launch.argtypes = [vp, vp]
-    lib.vv_debug_sweep_trace.argtypes = [vp, vp, i]
     lib.vv_reread_env.argtypes = [vp]
-    lib.vv_debug_plan_sweep.argtypes = [i, i, C.POINTER(camera_params), C.POINTER(vv_ray_source), C.POINTER(f * 3), i, i, i, i, i, i, vp]
     lib.vv_prepare_layouts.argtypes = [vp, i, vp]
     lib.vv_device_bytes.argtypes = [vp, vp]
     lib.vv_volume_dims.argtypes = [vp, C.POINTER(i * 3), C.POINTER(i)]
@@ -213,23 +210,6 @@ class Camera:
                               r * np.sin(theta) * np.sin(phi)), **kw)
 
 
-def plan_sweep(width: int, height: int, cam: "Camera", step: float, voxel_type: int, dims, phong: bool = False,
-               slice_type: int = SLICE_NONE, rays=None) -> dict:
-    """vv_debug_plan_sweep: the slab-sweep planner's decision for a frame (host arithmetic only, needs no GPU).  The sweep
-    kernel and its planner are part of the experimental build of the library only."""
-    lib = load_library(LIB_X_PATH)
-    cp = cam.params(width, height)
-    rs = rays if rays is not None else analytic_rays(cam)
-    st = (C.c_float * 3)(step, step, step) if np.isscalar(step) else (C.c_float * 3)(*step)
-    out = np.zeros(12, np.int32)
-    rc = lib.vv_debug_plan_sweep(width, height, C.byref(cp), C.byref(rs), C.byref(st), voxel_type, dims[0], dims[1], dims[2],
-                                 int(phong), slice_type, out.ctypes.data)
-    if rc:
-        raise VolvizError(rc, "vv_debug_plan_sweep")
-    keys = ("enabled", "major", "sgn", "wx", "wy", "pxc", "ry", "group", "ring", "ntx", "nty", "nl")
-    return dict(zip(keys, (int(v) for v in out)))
-
-
 def analytic_rays(cam: Camera, quantize8: bool = False, aspect: float = 0.0) -> vv_ray_source:
     rs = vv_ray_source()
     rs.mode = RAYS_ANALYTIC
@@ -279,7 +259,8 @@ def make_slice_params(slice_type: int = SLICE_NONE, point=(0.5, 0.5, 0.5), norma
 
 
 def make_options(step=None, ert_threshold=0.0, filter=FILTER_TEX8, ert_mode=ERT_REFERENCE,
-                 slab_rows=(0, 0), shard=None, count_samples=False, touched_bricks=0) -> vv_render_options:
+                 slab_rows=(0, 0), shard=None, count_samples=False, touched_bricks=0, touched_lines=0, touched_line_bits=0,
+                 touched_lines_all=False) -> vv_render_options:
     o = vv_render_options()
     if step is not None:
         s = [step] * 3 if np.isscalar(step) else list(step)
@@ -292,6 +273,9 @@ def make_options(step=None, ert_threshold=0.0, filter=FILTER_TEX8, ert_mode=ERT_
         o.shard_band, o.shard_count, o.shard_index = shard
     o.count_samples = int(count_samples)
     o.touched_bricks = touched_bricks
+    o.touched_lines = touched_lines
+    o.touched_line_bits = touched_line_bits
+    o.touched_lines_all = int(touched_lines_all)
     return o
 
 
@@ -421,13 +405,6 @@ class Context:
     def reread_env(self):
         """vv_reread_env: pick up VV_* knobs changed since the last volume load."""
         self._chk(self.lib.vv_reread_env(self.h))
-
-    def sweep_trace(self, max_blocks: int = 65536):
-        out = np.zeros((max_blocks, 8), np.uint64)
-        n = self.lib.vv_debug_sweep_trace(self.h, out.ctypes.data, max_blocks)
-        if n < 0:
-            raise VolvizError(n, "no sweep trace (render with VV_SWEEP_TRACE=1)")
-        return out[:n]
 
     def last_sample_count(self) -> int:
         return int(self.lib.vv_last_sample_count(self.h))
