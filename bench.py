@@ -3,6 +3,7 @@
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...        (no launcher: starts the N ranks itself, as a child torch.distributed.run, before any GPU call)
 
 One "step" = one frame: rad pre-pass + ray march of this rank's screen bands (+ one RCCL
 gather of RGBA8 bands to rank 0 when N > 1).  Inputs are resident in HBM before the timed
@@ -67,6 +68,23 @@ def measured_traffic(key):
     return j.get("entries", {}).get(key), None
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `python -m torch.distributed.run` (one process per GPU,
+    rendezvous on 127.0.0.1) and return its exit code -- a rank that fails makes the launcher stop the others and return non-zero.  This
+    process has not touched a GPU (importing torch does not), and it never replaces itself: it waits for the child and exits with its code."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def workload(args, world):
     if args.config == "c3":
         n = 1024
@@ -107,8 +125,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        sys.exit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))                     # before any GPU call of this process
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    if os.environ.get("VV_BENCH_DRYRUN") == "1":
+        # rehearsal of the launch path without a device (tests/test_sharding.py, CPU): rendezvous, one collective, the line's frame -- then stop
+        if os.environ.get("VV_BENCH_DRYRUN_FAIL") == str(rank):
+            sys.exit(3)                                      # (a rank that dies: the launcher must report it)
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist.all_reduce(t)
+            ok = float(t[0]) == world * (world + 1) / 2
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            ok = True
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "collective": {"backend": "gloo", "ranks": world}, "all_reduce_ok": ok,
+                              "frame": list(workload(args, world)[1:3]), "local_rank": local}))
+        sys.exit(0 if ok else 1)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the product has no CPU path")
     # VV_BENCH_SHARE_GPU=1 (developer rehearsal on a 1-GPU box): every rank uses cuda:0 and the

@@ -3,6 +3,8 @@ the oracle, standing in for the GPU kernel, with the same shard predicate), then
 product's gather / re-assembly code (volviz_amd.sharding) exactly as bench.py does."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -141,3 +143,37 @@ def test_native_gather_band_bookkeeping():
                 assert got == want, (H, n, rb, re)
                 rk, ya, yb = C.c_int(), C.c_int(), C.c_int()
                 assert f(H, n, rb, re, nbands, C.byref(rk), C.byref(ya), C.byref(yb)) != 0      # band out of range
+
+
+def _bench(args, env_extra, timeout=600):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    repo = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    return subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command): bench.py starts the ranks itself, as a
+    child torch.distributed.run, before touching a GPU.  Rehearsed here without a device (VV_BENCH_DRYRUN=1: rendezvous on 127.0.0.1, one gloo
+    collective, then stop where device selection would begin): rank 0 prints one JSON line for N ranks with the N-GPU frame."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"VV_BENCH_DRYRUN": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["collective"]["ranks"] == 2 and j["all_reduce_ok"] and j["frame"] == [2716, 1528]
+
+
+def test_bench_reports_a_failed_rank():
+    """A rank that dies makes the whole command fail (non-zero exit, no JSON line taken for a result)."""
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"VV_BENCH_DRYRUN": "1", "VV_BENCH_DRYRUN_FAIL": "1"})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_a_mismatched_launcher():
+    r = _bench(["--gpus", "4"], {"VV_BENCH_DRYRUN": "1", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 4" in (r.stderr + r.stdout)

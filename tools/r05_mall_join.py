@@ -10,7 +10,8 @@ for d in ("pmc_ub", "pmc_ub2"):
         for r in csv.DictReader(open(f)):
             k = (r["Kernel_Name"].split("(")[0], int(r["Dispatch_Id"]))
             rows.setdefault(k, {})[r["Counter_Name"]] = float(r["Counter_Value"])
-variants = [l.rstrip("\n") for l in open(os.path.join(root, "mall_reread_pmc_run.txt")) if l[:1] not in "#" and l.strip()]
+import re
+variants = [l.rstrip("\n") for l in open(os.path.join(root, "mall_reread_pmc_run.txt")) if re.match(r"^(\s*\d+ |table)", l)]
 for kern in ("reread", "loop_read"):
     ids = sorted(i for (k, i) in rows if k.startswith(kern))
     vs = [v for v in variants if (v.startswith("table") == (kern == "loop_read"))]
