@@ -233,6 +233,10 @@ int  vv_first_pass(vv_context *ctx, int img_w, int img_h, const struct camera_pa
  * and the orientation rule applied before the plane goes into slice_params (glwidget.cpp:243-258:
  * the normal is negated when flip_cross_section && n.y < -1e-6, or !flip && n.y > 1e-6).       */
 int  vv_cut_plane_canonical(int orientation, float displace, float point[3], float normal[3]);
+/* Cutting plane of the free-form ("pro") slice view: Window::renderSlice's PRO_SLICING branch (window.cpp:425-443), which hands
+ * GLWidget::setSlicePro (glwidget.cpp:743-755)  point = (dx, dy, dz) + .5  and  normal = T(.5) Rx(theta) Ry(phi) Rz(psi) T(-.5) (0,0,1,0),
+ * binary32 with the operation order of cs123math (bit-identical to the compiled reference: tests/golden/cut_planes_pro.json).  Host-only. */
+int  vv_cut_plane_from_euler(float dx, float dy, float dz, float theta, float phi, float psi, float point[3], float normal[3]);
 int  vv_cut_plane_to_slice_params(int slice_type, const float point[3], const float normal[3],
                                   int flip_cross_section, struct slice_params *out);
 

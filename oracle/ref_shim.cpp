@@ -103,4 +103,20 @@ void ref_slice_matrix(float dx, float dy, float dz, float theta, float phi, floa
     memcpy(out, m.data, 16 * sizeof(float));
 }
 
+/* The cutting plane Window::renderSlice hands GLWidget::setSlicePro for the free-form slice view (window.cpp:425-441), composed with the
+ * reference's own builders and operators exactly as that code writes it. */
+void ref_cut_plane_pro(float dx, float dy, float dz, float theta, float phi, float psi, float point[3], float normal[3])
+{
+    Vector4 offset = Vector4(dx, dy, dz, 0);
+    offset += Vector4(0.5, 0.5, 0.5, 0);
+    Matrix4x4 trans = getTransMat(Vector4(0.5, 0.5, 0.5, 1.0));
+    Matrix4x4 rotX = getRotXMat(theta);
+    Matrix4x4 rotY = getRotYMat(phi);
+    Matrix4x4 rotZ = getRotZMat(psi);
+    Matrix4x4 transBack = getTransMat(Vector4(-0.5, -0.5, -0.5, 1.0));
+    Vector4 n = trans * rotX * rotY * rotZ * transBack * Vector4(0, 0, 1, 0);
+    point[0] = offset.x; point[1] = offset.y; point[2] = offset.z;
+    normal[0] = n.x; normal[1] = n.y; normal[2] = n.z;
+}
+
 }

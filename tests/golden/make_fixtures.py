@@ -71,6 +71,22 @@ def frame_cases():
 PLANE_POINT, PLANE_NORMAL = (0.5, 0.5, 0.45), (0.2, -0.3, 0.93)
 
 
+def make_cut_planes(ref):
+    """cut_planes_pro.json: the cutting plane of the free-form slice view (window.cpp:425-441 -> GLWidget::setSlicePro) from the compiled
+    reference (oracle/ref_shim.cpp ref_cut_plane_pro): slider-like values (offsets in [-1, 1], angles in [-pi, pi] as the sliders give them,
+    window.cpp:408-414) and a few wild ones."""
+    rng = np.random.default_rng(11)
+    params = [(0, 0, 0, 0, 0, 0), (0.1, -0.2, 0.3, 0.5, -1.0, 2.0), (0, 0, 0, float(np.float32(np.pi)), 0, 0), (0, 0, 0, 0, float(np.float32(np.pi / 2)), 0)] + \
+             [tuple(float(np.float32(v)) for v in np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(-np.pi, np.pi, 3)])) for _ in range(20)] + \
+             [tuple(float(np.float32(v)) for v in np.concatenate([rng.uniform(-9, 9, 3), rng.uniform(-40, 40, 3)])) for _ in range(6)]
+    planes = []
+    for p in params:
+        pt = np.zeros(3, np.float32); n = np.zeros(3, np.float32)
+        ref.ref_cut_plane_pro(*p, pt.ctypes.data, n.ctypes.data)
+        planes.append(dict(params=list(p), point_hex=pt.tobytes().hex(), normal_hex=n.tobytes().hex()))
+    json.dump(planes, open(os.path.join(HERE, "cut_planes_pro.json"), "w"), indent=1)
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit(f"reference tree {REF} not present")
@@ -120,6 +136,8 @@ def main():
         mats.append(dict(params=list(p), matrix_hex=m.tobytes().hex()))
     json.dump(mats, open(os.path.join(HERE, "slice_matrices.json"), "w"), indent=1)
 
+    make_cut_planes(ref)
+
     # --- oracle-rendered frames -----------------------------------------------------------
     vols = {"brain32": b32, "brain64": O.draw_default_brain(64, 64, 64)}
     tfs = {"engine": vv.TF_ENGINE, "head": vv.TF_HEAD, "mri": vv.TF_MRI}
@@ -141,4 +159,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "cut_planes":          # only the fixture added in round 5 (the others are unchanged)
+        make_cut_planes(O.ref())
+    else:
+        main()

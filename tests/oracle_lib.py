@@ -80,6 +80,8 @@ def ref():
         lib.ref_save_default_brain.argtypes = [C.c_char_p, i, i, i, i]
         lib.ref_load_raw.argtypes = [C.c_char_p, i, vp, C.c_long, vp]; lib.ref_load_raw.restype = C.c_long
         lib.ref_slice_matrix.argtypes = [f, f, f, f, f, f, vp]
+        if hasattr(lib, "ref_cut_plane_pro"):
+            lib.ref_cut_plane_pro.argtypes = [f, f, f, f, f, f, vp, vp]
         _ref = lib
     return _ref
 

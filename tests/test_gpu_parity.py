@@ -1291,6 +1291,7 @@ def test_touched_lines_instrument(ctx, monkeypatch):
     dev = torch.device("cuda", 0)
     frame = torch.zeros(H * W, dtype=torch.int32, device=dev)
     counts = {}
+    monkeypatch.setenv("VV_ZPAIR", "0")                        # (the policy would give this small unshaded front view the z-pair copy)
     for env in ({"VV_BRICKED": "0"}, {"VV_BRICKED": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -53,6 +53,29 @@ def test_slice_matrix_matches_reference(golden_dir):
         vv.slice_matrix(0, 0, 0, 3.3, 0, 0)
 
 
+def test_cut_plane_from_euler_matches_reference(golden_dir):
+    """vv_cut_plane_from_euler = the plane Window::renderSlice hands GLWidget::setSlicePro (window.cpp:425-443), bit for bit against planes
+    the compiled reference's own operators produced (tests/golden/cut_planes_pro.json, make_fixtures.py cut_planes), and -- where the
+    compiled reference is present -- against it directly on fresh random sliders."""
+    for case in json.load(open(os.path.join(golden_dir, "cut_planes_pro.json"))):
+        pt, n = vv.cut_plane_from_euler(*case["params"])
+        assert pt.tobytes().hex() == case["point_hex"] and n.tobytes().hex() == case["normal_hex"], case["params"]
+    pt, n = vv.cut_plane_from_euler(0, 0, 0, 0, 0, 0)
+    assert pt.tolist() == [0.5, 0.5, 0.5] and n.tolist() == [0.0, 0.0, 1.0]            # the sagittal plane through the centre
+    pt, n = vv.cut_plane_from_euler(0.25, 0, 0, 0, float(np.float32(np.pi / 2)), 0)      # Ry(90 deg) turns +z into +x
+    assert np.allclose(n, [1, 0, 0], atol=1e-6) and pt.tolist() == [0.75, 0.5, 0.5]
+    import oracle_lib as O                       # (only its loader of the compiled reference, oracle/_ref/libvvref.so)
+    ref = O.ref()
+    if ref is not None and hasattr(ref, "ref_cut_plane_pro"):
+        rng = np.random.default_rng(2025)
+        for _ in range(300):
+            p = [float(np.float32(v)) for v in np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(-7, 7, 3)])]
+            rp = np.zeros(3, np.float32); rn = np.zeros(3, np.float32)
+            ref.ref_cut_plane_pro(*p, rp.ctypes.data, rn.ctypes.data)
+            pt, n = vv.cut_plane_from_euler(*p)
+            assert pt.tobytes() == rp.tobytes() and n.tobytes() == rn.tobytes(), p
+
+
 def test_t3d_reads_reference_written_file(golden_dir, tmp_path):
     lib = vv.load_library()
     p = os.path.join(golden_dir, "brain_16.t3d").encode()

@@ -98,7 +98,7 @@ def test_paint_loop_symbols():
     """CPU check: the GLWidget-shaped loop (host/paint_loop.h) is part of the mirror library."""
     so = os.path.join(REPO, "volume-viz_amd", "lib", "libvolviz_host.so")
     out = subprocess.check_output(["nm", "-D", "-C", "--defined-only", so]).decode()
-    for name in ("PaintLoop::paintGL()", "PaintLoop::resizeGL(int, int)", "PaintLoop::orbitDrag(int, int)", "PaintLoop::setSliceCanonical(int, float)",
+    for name in ("PaintLoop::paintGL()", "PaintLoop::resizeGL(int, int)", "PaintLoop::orbitDrag(int, int)", "PaintLoop::setSliceCanonical(int, float)", "PaintLoop::setSlicePro(float, float, float, float, float, float)",
                  "PaintLoop::loadVolume(char const*)"):
         assert name in out, name
 
@@ -113,7 +113,7 @@ def test_paint_loop_matches_oracle(tmp_path):
     ww, wh = 510, 384
     r = subprocess.run([demo, str(tmp_path), str(ww), str(wh)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "3 of 4 paints marched" in r.stdout, r.stdout
+    assert "4 of 5 paints marched" in r.stdout, r.stdout
     W, H = ww // 3, wh // 3
     vol = O.draw_default_brain(64, 64, 64)
     tf = O.transfer_preset(vv.TF_ENGINE)
@@ -122,9 +122,11 @@ def test_paint_loop_matches_oracle(tmp_path):
     pos2 = vv.camera_zoom(pos1, look1, 60)
     pt, nrm = vv.cut_plane_canonical(vv.CORONAL, 0.1)
     sp2 = vv.cut_plane_to_slice_params(vv.SLICE_PLANE_CUT, pt, nrm, False)
-    sessions = [(pos0, -pos0, None, False), (pos1, look1, None, True), (pos2, look1, sp2, True)]
+    ppt, pnrm = vv.cut_plane_from_euler(0.05, -0.1, 0.02, 0.4, -0.7, 1.1)       # PaintLoop::setSlicePro(dx, dy, dz, theta, phi, psi): window.cpp:425-443
+    sp4 = vv.cut_plane_to_slice_params(vv.SLICE_PLANE_CUT, ppt, pnrm, False)
+    sessions = [(0, pos0, -pos0, None, False), (1, pos1, look1, None, True), (2, pos2, look1, sp2, True), (4, pos2, look1, sp4, True)]
     lit = 0
-    for k, (pos, look, sp, phong) in enumerate(sessions):
+    for k, pos, look, sp, phong in sessions:
         front = np.fromfile(tmp_path / f"front{k}.rgba", np.uint8).reshape(wh, ww, 4)
         back = np.fromfile(tmp_path / f"back{k}.rgba", np.uint8).reshape(wh, ww, 4)
         cam_w = vv.Camera(origin=tuple(float(v) for v in pos))
@@ -136,7 +138,7 @@ def test_paint_loop_matches_oracle(tmp_path):
         want, _ = O.render(vol, tf, W, H, cam_w, slice=sp, phong=phong, rays=vv.image_rays(front, back), fill=0)
         assert np.array_equal(got, want), f"frame {k}"
         lit += int((got[..., 3] > 0).sum())
-    assert lit > 3 * W * H // 20
+    assert lit > 4 * W * H // 20
 
 
 def test_dataset_presets_follow_the_file_name():
@@ -165,7 +167,7 @@ def test_paint_loop_load_volume(tmp_path):
     ww, wh = 510, 384
     r = subprocess.run([demo, str(tmp_path), str(ww), str(wh), str(t3d)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "4 of 5 paints marched" in r.stdout and "preset 0 scale 1 1 0.8" in r.stdout, r.stdout
+    assert "5 of 6 paints marched" in r.stdout and "preset 0 scale 1 1 0.8" in r.stdout, r.stdout
     W, H = ww // 3, wh // 3
     raw = np.fromfile(src, np.uint8)
     dims = np.frombuffer(raw[:24].tobytes(), "<u8")

@@ -99,6 +99,36 @@ int vv_slice_matrix(float dx, float dy, float dz, float theta, float phi, float 
     return VV_OK;
 }
 
+// Window::renderSlice, PRO_SLICING branch (window.cpp:425-443): the cutting plane the free-form slice sliders give the 3D view.
+//   offset = Vector4(dx, dy, dz, 0) += Vector4(.5, .5, .5, 0)                                         (binary32 additions)
+//   normal = getTransMat(.5) * getRotXMat(theta) * getRotYMat(phi) * getRotZMat(psi) * getTransMat(-.5) * Vector4(0, 0, 1, 0)
+// evaluated as the reference's operators do: the matrix products left to right (mat4::operator*=, CS123Algebra.h:429-471: each element
+// a sum of four products in index order), then mat4 * vec4 (CS123Algebra.h:340-345).  The translations drop out of the result in exact
+// arithmetic; they are kept because they take part in the float sums.  Pinned bit for bit against the compiled reference
+// (oracle/ref_shim.cpp ref_cut_plane_pro, tests/golden/cut_planes_pro.json).  No angle range is asserted on this path.
+int vv_cut_plane_from_euler(float dx, float dy, float dz, float theta, float phi, float psi, float point[3], float normal[3])
+{
+    if (!point || !normal) return VV_ERR_INVALID;
+    auto mul = [](const float a[16], const float b[16], float r[16]) {
+        float t[16];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                t[4*i+j] = a[4*i] * b[j] + a[4*i+1] * b[4+j] + a[4*i+2] * b[8+j] + a[4*i+3] * b[12+j];
+        memcpy(r, t, sizeof t);
+    };
+    const float ct = cosf(theta), st = sinf(theta), cp = cosf(phi), sp = sinf(phi), cs = cosf(psi), ss = sinf(psi);
+    const float rx[16] = {1, 0, 0, 0, 0, ct, -st, 0, 0, st, ct, 0, 0, 0, 0, 1};
+    const float ry[16] = {cp, 0, sp, 0, 0, 1, 0, 0, -sp, 0, cp, 0, 0, 0, 0, 1};
+    const float rz[16] = {cs, -ss, 0, 0, ss, cs, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    float m[16] = {1, 0, 0, 0.5f, 0, 1, 0, 0.5f, 0, 0, 1, 0.5f, 0, 0, 0, 1};
+    const float tb[16] = {1, 0, 0, -0.5f, 0, 1, 0, -0.5f, 0, 0, 1, -0.5f, 0, 0, 0, 1};
+    mul(m, rx, m); mul(m, ry, m); mul(m, rz, m); mul(m, tb, m);
+    const float v[4] = {0.f, 0.f, 1.f, 0.f};
+    for (int i = 0; i < 3; ++i) normal[i] = m[4*i] * v[0] + m[4*i+1] * v[1] + m[4*i+2] * v[2] + m[4*i+3] * v[3];
+    point[0] = dx + 0.5f; point[1] = dy + 0.5f; point[2] = dz + 0.5f;
+    return VV_OK;
+}
+
 // GLWidget::setSliceCanonical, glwidget.cpp:757-776
 int vv_cut_plane_canonical(int orientation, float displace, float point[3], float normal[3])
 {

@@ -128,9 +128,23 @@ void PaintLoop::setCuttingPlane(const float point[3], const float normal[3], boo
 }
 void PaintLoop::setSliceCanonical(int orientation, float displace)
 {
+    if (m_sliceVis == 0) return;                                       // glwidget.cpp:761: only while a slice visualisation is on
     int rc = vv_cut_plane_canonical(orientation, displace, m_cutPoint, m_cutNormal);
     if (rc) die("vv_cut_plane_canonical", rc);
-    m_hasCuttingPlane = true; m_renderingDirty = true;
+    m_flip = false; m_hasCuttingPlane = true; m_renderingDirty = true;
+}
+void PaintLoop::setSlicePro(const float offset[3], const float normal[3])
+{
+    if (m_sliceVis == 0) return;                                       // glwidget.cpp:745
+    for (int a = 0; a < 3; ++a) { m_cutPoint[a] = offset[a]; m_cutNormal[a] = normal[a]; }
+    m_flip = false; m_hasCuttingPlane = true; m_renderingDirty = true;  // :746-753
+}
+void PaintLoop::setSlicePro(float dx, float dy, float dz, float theta, float phi, float psi)
+{
+    float pt[3], n[3];
+    int rc = vv_cut_plane_from_euler(dx, dy, dz, theta, phi, psi, pt, n);
+    if (rc) die("vv_cut_plane_from_euler", rc);
+    setSlicePro(pt, n);
 }
 void PaintLoop::clearCuttingPlane() { m_hasCuttingPlane = false; m_renderingDirty = true; }
 void PaintLoop::setResolutionScale(int s) { if (s >= 1) { m_resolutionScale = s; if (m_width) resizeGL(m_width, m_height); } }

@@ -41,7 +41,10 @@ public:
     void setPhongShading(bool on);
     void setSliceVisualization(int vis /* 0 none, 1 plane, 2 cross section (glwidget.h sliceVisualization) */);
     void setCuttingPlane(const float point[3], const float normal[3], bool flipCrossSection);
-    void setSliceCanonical(int orientation, float displace);           // :743-788
+    void setSliceCanonical(int orientation, float displace);           // :757-788 (ignored while the slice visualisation is off, as in the reference)
+    void setSlicePro(const float offset[3], const float normal[3]);    // :743-755: the free-form slice view's plane (vv_cut_plane_from_euler makes it from the sliders, window.cpp:425-443)
+    void setSlicePro(float dx, float dy, float dz, float theta, float phi, float psi);   // Window::renderSlice's PRO_SLICING branch + setSlicePro in one call
+    bool hasCuttingPlane() const { return m_hasCuttingPlane; }
     void clearCuttingPlane();
     void setResolutionScale(int s);                                    // params.h:10 (3 in the reference)
 

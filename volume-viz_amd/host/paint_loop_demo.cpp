@@ -41,10 +41,15 @@ int main(int argc, char **argv)
     gl.orbitDrag(37, -21); gl.setPhongShading(true);
     marched += gl.paintGL();
     dump(out + "/frame1.rgba", gl.resultTexture()); dump(out + "/front1.rgba", gl.frontFace()); dump(out + "/back1.rgba", gl.backFace());
-    gl.setSliceCanonical(CORONAL, 0.1f); gl.setSliceVisualization(2); gl.zoom(60);
+    gl.setSliceCanonical(CORONAL, 0.3f);                            // no slice visualisation yet: ignored (glwidget.cpp:761)
+    if (gl.hasCuttingPlane() || gl.renderingDirty()) { fprintf(stderr, "setSliceCanonical took effect without a slice visualisation\n"); return 1; }
+    gl.setSliceVisualization(2); gl.setSliceCanonical(CORONAL, 0.1f); gl.zoom(60);
     marched += gl.paintGL();
     dump(out + "/frame2.rgba", gl.resultTexture()); dump(out + "/front2.rgba", gl.frontFace()); dump(out + "/back2.rgba", gl.backFace());
-    int expected = 3;
+    gl.setSlicePro(0.05f, -0.1f, 0.02f, 0.4f, -0.7f, 1.1f);         // the free-form slice sliders (window.cpp:405-443 -> setSlicePro)
+    marched += gl.paintGL();
+    dump(out + "/frame4.rgba", gl.resultTexture()); dump(out + "/front4.rgba", gl.frontFace()); dump(out + "/back4.rgba", gl.backFace());
+    int expected = 4;
     if (argc == 5) {
         gl.loadVolume(argv[4]);                                     // window.cpp:347-351 -> glwidget.cpp:668-710
         marched += gl.paintGL(); ++expected;

@@ -77,7 +77,7 @@ EXPORTS = [
     "vv_promote_u8_to_f32", "vv_generate_noise_u8", "vv_transfer_preset",
     "vv_t3d_read_header", "vv_t3d_read", "vv_t3d_write", "vv_last_frame_ms",
     "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid", "vv_debug_counters",
-    "vv_first_pass", "vv_cut_plane_canonical", "vv_cut_plane_to_slice_params", "vv_slice_to_bgra",
+    "vv_first_pass", "vv_cut_plane_canonical", "vv_cut_plane_from_euler", "vv_cut_plane_to_slice_params", "vv_slice_to_bgra",
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
     "vv_prepare_layouts", "vv_device_bytes", "vv_reread_env",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
@@ -134,6 +134,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_slice_matrix.argtypes = [f, f, f, f, f, f, vp]
     lib.vv_first_pass.argtypes = [vp, i, i, C.POINTER(camera_params), C.POINTER(vv_ray_source), vp, vp, i, vp]
     lib.vv_cut_plane_canonical.argtypes = [i, f, vp, vp]
+    lib.vv_cut_plane_from_euler.argtypes = [f, f, f, f, f, f, vp, vp]
     lib.vv_cut_plane_to_slice_params.argtypes = [i, vp, vp, i, C.POINTER(slice_params)]
     lib.vv_slice_to_bgra.argtypes = [vp, sz, sz, vp]
     lib.vv_camera_orbit_drag.argtypes = [vp, i, i, vp, vp]
@@ -481,6 +482,15 @@ def cut_plane_canonical(orientation: int, displace: float):
     rc = load_library().vv_cut_plane_canonical(orientation, displace, pt.ctypes.data, n.ctypes.data)
     if rc:
         raise VolvizError(rc, "bad orientation")
+    return pt, n
+
+
+def cut_plane_from_euler(dx, dy, dz, theta, phi, psi):
+    """vv_cut_plane_from_euler: the free-form slice view's cutting plane (window.cpp:425-443 -> GLWidget::setSlicePro) -> (point, normal)."""
+    pt = np.zeros(3, np.float32); n = np.zeros(3, np.float32)
+    rc = load_library().vv_cut_plane_from_euler(dx, dy, dz, theta, phi, psi, pt.ctypes.data, n.ctypes.data)
+    if rc:
+        raise VolvizError(rc, "bad argument")
     return pt, n
 
 
