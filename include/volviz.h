@@ -122,7 +122,9 @@ typedef struct vv_ray_source {
      * images, if the host knows it (glwidget.cpp:188-228 draws them from `camera`).  With a hint vv_render
      * chooses wave tiles, volume layout and occupancy as for analytic rays; without one it estimates the
      * view from the images' centre row (host images; device images only in synchronous calls, which may
-     * read them back) and otherwise launches conservatively.  Leave look / up zero for "no hint".      */
+     * read them back) and otherwise launches conservatively.  Leave look / up zero for "no hint": ZERO-INITIALISE this struct -- stale
+     * values in look / up of an image source are read as a camera and pick tile shape, layout (possibly building a copy of the volume)
+     * and occupancy from it; a non-finite or degenerate hint is ignored.  Device images must be 4-byte aligned (VV_ERR_INVALID otherwise). */
     float          look[3];
     float          up[3];
     float          aspect;           /* <= 0 : use W/H */
@@ -314,19 +316,31 @@ int  vv_t3d_read_header(const char *path, int header, int *nx, int *ny, int *nz)
 int  vv_t3d_read (const char *path, int header, uint8_t *dst, size_t capacity);
 int  vv_t3d_write(const char *path, int header, const uint8_t *src, int nx, int ny, int nz);
 
-/* ---- optional second layouts of the loaded volume (no reference counterpart: cudaArray hides its
- * layout).  vv_render builds them by itself on the first frame that profits (a few ms once, and a
- * stream synchronisation); a host that wants the first frame at full speed builds them up front.
- *   VV_LAYOUT_BRICKED  4x4x4-voxel bricks with an x halo (1.25x an f32 volume, 2x a u8 volume): sampled
- *                      when the screen x direction is more than ~14 degrees off the volume's x axis
- *   VV_LAYOUT_ZPAIR    {v(z), v(z+1)} records (2x the volume): sampled by unshaded frames along the x
- *                      axis, f32 volumes up to 512 MiB and u8 volumes up to 2 GiB
- * Both are dropped when another volume is loaded; results never depend on which layout is sampled.
- * Returns the bit mask of the requested layouts that are resident afterwards (a layout that does
- * not fit in free HBM is skipped, not an error), or a negative vv_status.                     */
-enum { VV_LAYOUT_BRICKED = 1, VV_LAYOUT_ZPAIR = 2, VV_LAYOUT_ZFAST = 4 /* f32: rows along z, for side views */ };
+/* ---- optional second layouts of the loaded volume (no reference counterpart: cudaArray hides its layout) -----------------------
+ * Which copy a frame samples is a launch-policy decision; results never depend on it.
+ *   VV_LAYOUT_BRICKED  4x4x4-voxel bricks with an x halo (1.25x an f32 volume, 2x a u8 volume): frames whose screen x direction is more
+ *                      than ~14 degrees off the volume's x and z axes; volumes of 2 M voxels and more
+ *   VV_LAYOUT_ZFAST    rows along z (1x the volume, both voxel types): side views (screen x within ~14 degrees of the volume's z axis).
+ *                      Preparing it also builds the x-pair copy (2x) where the policy would sample it (unshaded side views of u8 volumes
+ *                      and of f32 volumes up to 512 MiB)
+ *   VV_LAYOUT_ZPAIR    {v(z), v(z+1)} records (2x the volume): unshaded frames along the x axis, f32 up to 512 MiB, u8 up to 2 GiB
+ *   VV_LAYOUT_POLICY   every copy of the above that vv_render's policy can pick for the loaded volume
+ * RESIDENCY.  All copies together stay within a budget: by default the larger of 8 GiB and 2.5 x the linear volume (C3's 4.3 GB volume: the
+ * bricked + z-fastest copies, 9.7 GB; C5's 32 GiB volume: 72 GiB), vv_set_layout_policy changes it.  A copy that does not fit evicts the
+ * copies sampled least recently; if that is not enough it is not built and frames take the next layout of the policy (at worst the linear
+ * volume).  By default vv_render builds a missing copy on the first frame that wants it: a kernel over the volume (1024^3 f32: bricked 4.2 ms,
+ * z-fastest 2.5 ms; x 8 at 2048^3), a hipMalloc and a stream synchronisation -- also inside an enqueue-only call.  A host that must not
+ * stall in its paint loop calls vv_prepare_layouts(VV_LAYOUT_POLICY) after loading (the mirror's cudaLoadVolume and PaintLoop::loadVolume
+ * do) and may switch building in vv_render off (build_in_render = 0): frames then sample what is resident.
+ * All copies are dropped when another volume is loaded.
+ * vv_prepare_layouts returns the bit mask of the requested layouts that are resident afterwards, or a negative vv_status.               */
+enum { VV_LAYOUT_BRICKED = 1, VV_LAYOUT_ZPAIR = 2, VV_LAYOUT_ZFAST = 4, VV_LAYOUT_POLICY = 256 };
 int  vv_prepare_layouts(vv_context *ctx, int which, void *stream);
-/* Device memory held by the context: out[0] linear volume, [1] bricked copy, [2] z-pair + z-fastest copies,
+int  vv_set_layout_policy(vv_context *ctx, unsigned long long budget_bytes /* 0 = default */, int build_in_render /* default 1 */);
+/* out = { linear volume, bricked, z-pair, z-fastest, x-pair copy (bytes; 0 = not resident), budget for the copies, copies built inside
+ *         vv_render since the volume was loaded, build_in_render } */
+int  vv_layout_state(const vv_context *ctx, unsigned long long out[8]);
+/* Device memory held by the context: out[0] linear volume, [1] bricked copy, [2] z-pair + z-fastest + x-pair copies,
  * [3] tables and scratch (bytes). */
 int  vv_device_bytes(const vv_context *ctx, unsigned long long out[4]);
 

@@ -1312,3 +1312,65 @@ def test_touched_lines_instrument(ctx, monkeypatch):
     assert vol_lines <= counts["0"] <= vol_lines + n + 4, counts                # every row of the volume + at most the first padding slice's rows (weight-0 corners)
     brick_lines = (n // 4) ** 3 * 320 // 128                                    # 1280
     assert brick_lines <= counts["1"] <= brick_lines + 2 * (n // 4) * (n // 4 + 1) * 3 + 64, counts      # every brick + at most the clamped extra layers in y and z
+
+
+def test_layout_residency_policy(monkeypatch):
+    """Residency of the optional copies (include/volviz.h): vv_prepare_layouts(VV_LAYOUT_POLICY) builds what the launch policy can pick, frames then
+    build nothing; with building in vv_render switched off a frame samples what is resident (at worst the linear volume); a budget too small for
+    all copies evicts the one sampled least recently.  Frames equal the oracle's throughout."""
+    for k in ("VV_BRICKED", "VV_ZPAIR", "VV_ZFAST"):
+        monkeypatch.delenv(k, raising=False)
+    n = 128                                                        # 2 M voxels: the policy's threshold for the bricked / z-fastest copies
+    vol = O.noise_u8(n, n, n, 9).astype(np.float32) / np.float32(255)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    W, H = 150, 110
+    views = {"front": vv.Camera(), "side": vv.Camera(origin=(-4.0, 0.0, 0.0)), "oblique": vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5)}
+    want = {k: O.render(vol, tf, W, H, cam, options=vv.make_options(step=1 / 128))[0] for k, cam in views.items()}
+    o = vv.make_options(step=1 / 128)
+    with vv.Context(0) as c:
+        c.load_volume(vol, tf)
+        st = c.layout_state()
+        assert st["bricked"] == st["zpair"] == st["zfast"] == st["xpair"] == 0 and st["budget"] >= 8 << 30 and st["build_in_render"] == 1
+        # (1) built by the frames that want them (the default): one build per copy, none on the second round
+        lay = {}
+        for rnd in range(2):
+            for k, cam in views.items():
+                assert np.array_equal(c.render(W, H, cam, options=o), want[k]), k
+                lay[k] = c.last_launch()["layout"]
+            assert c.layout_state()["builds_in_render"] == 4, c.layout_state()       # z-pair (front), z-fastest + x-pair (side), bricked (oblique)
+        assert lay == {"front": 3, "side": 5, "oblique": 2}, lay
+        # (2) prepared up front, frames build nothing
+        c.load_volume(vol, tf)
+        assert c.prepare_layouts(vv.LAYOUT_POLICY) == vv.LAYOUT_BRICKED | vv.LAYOUT_ZPAIR | vv.LAYOUT_ZFAST
+        st = c.layout_state()
+        assert min(st["bricked"], st["zpair"], st["zfast"], st["xpair"]) > 0 and st["builds_in_render"] == 0
+        c.set_layout_policy(0, False)
+        for k, cam in views.items():
+            assert np.array_equal(c.render(W, H, cam, options=o), want[k]), k
+            assert c.last_launch()["layout"] == lay[k]
+        assert c.layout_state()["builds_in_render"] == 0
+        # (3) nothing resident and no building in vv_render: every view on the linear volume
+        c.load_volume(vol, tf)
+        c.set_layout_policy(0, False)
+        for k, cam in views.items():
+            assert np.array_equal(c.render(W, H, cam, options=o), want[k]), k
+            assert c.last_launch()["layout"] in (0, 1), (k, c.last_launch())
+        st = c.layout_state()
+        assert st["bricked"] == st["zpair"] == st["zfast"] == st["xpair"] == 0
+        # (4) a budget that holds the bricked copy OR the side-view copies, not both: the least recently sampled goes
+        c.load_volume(vol, tf)
+        vb = c.layout_state()["linear"]
+        c.set_layout_policy(int(3.3 * vb), True)
+        assert np.array_equal(c.render(W, H, views["side"], options=o), want["side"])
+        st = c.layout_state(); assert st["zfast"] > 0 and st["xpair"] > 0 and st["bricked"] == 0
+        assert np.array_equal(c.render(W, H, views["oblique"], options=o), want["oblique"])
+        st = c.layout_state(); assert st["bricked"] > 0 and st["bricked"] + st["zfast"] + st["xpair"] + st["zpair"] <= st["budget"], st
+        assert st["zfast"] == 0 or st["xpair"] == 0, st                                  # something of the side view's had to go
+        assert np.array_equal(c.render(W, H, views["side"], options=o), want["side"])    # ... and comes back, evicting in turn
+        st = c.layout_state(); assert st["bricked"] + st["zfast"] + st["xpair"] + st["zpair"] <= st["budget"], st
+        # (5) a budget below any copy: frames stay on the linear volume
+        c.load_volume(vol, tf)
+        c.set_layout_policy(vb // 2, True)
+        for k, cam in views.items():
+            assert np.array_equal(c.render(W, H, cam, options=o), want[k]), k
+            assert c.last_launch()["layout"] in (0, 1)

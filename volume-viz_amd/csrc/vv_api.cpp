@@ -50,6 +50,11 @@ struct vv_context {
     void *d_zpair = nullptr; bool zpair_valid = false; uint32_t zp_row = 0, zp_slab = 0; size_t zpair_bytes = 0;
     void *d_zfast = nullptr; bool zfast_valid = false, zfast_failed = false; uint32_t zf_row = 0; uint64_t zf_slice = 0; size_t zfast_bytes = 0;   // z-fastest copy (side views)
     void *d_xpair = nullptr; bool xpair_valid = false, xpair_failed = false; uint32_t xp_row = 0, xp_slab = 0; size_t xpair_bytes = 0;           // x-pair copy (side views of small / u8 volumes)
+    // residency policy of the optional copies (vv_set_layout_policy): HBM budget for all of them together (0 = default, layout_budget()),
+    // whether vv_render may build a missing copy by itself, and when each copy was last sampled (the least recently used one goes first)
+    size_t layout_budget_bytes = 0; bool build_in_render = true;
+    unsigned long long frame_no = 0, last_used[4] = {0, 0, 0, 0};          // CP_BRICKS, CP_ZPAIR, CP_ZFAST, CP_XPAIR
+    unsigned long long builds_in_render = 0;                                  // copies built inside vv_render since the volume was loaded
     // transfer function
     float4 *d_tf = nullptr; bool tf_gray = false; bool have_tf = false;
     bool tf_alpha_unit = false;          // every opacity of the table lies in [0, 1]: accumulated opacity never decreases
@@ -104,6 +109,9 @@ static void drop_bricks(vv_context *c)
     c->d_zfast = nullptr; c->zfast_valid = false; c->zfast_failed = false; c->zfast_bytes = 0;
     if (c->d_xpair) (void)hipFree(c->d_xpair);
     c->d_xpair = nullptr; c->xpair_valid = false; c->xpair_failed = false; c->xpair_bytes = 0;
+    for (int k = 0; k < 4; ++k) c->last_used[k] = 0;
+    c->builds_in_render = 0;
+    c->view_key_valid = false;             // (a new volume: the launch-policy estimate taken from first-pass images is re-taken)
 }
 
 static int ensure(vv_context *c, void **p, size_t *cap, size_t need)
@@ -170,6 +178,45 @@ static bool ensure_bricks(vv_context *c, hipStream_t st);
 static bool ensure_zpair(vv_context *c, hipStream_t st);
 static bool ensure_zfast(vv_context *c, hipStream_t st);
 static bool ensure_xpair(vv_context *c, hipStream_t st);
+
+// ---- residency of the optional copies -----------------------------------------------------------------------------------------
+// All copies of a volume together stay within a budget (default: the larger of 8 GiB and 2.5 x the linear volume -- room for the bricked and the
+// z-fastest copy of an f32 volume, C3: 9.7 GB of copies beside the 4.3 GB volume, C5: 72 GiB beside 32 GiB; every copy of a u8 volume up to 1 GiB).
+// A copy that would not fit evicts copies no frame has sampled more recently (least recently used first); if that is not enough it is not built
+// and the frame takes the next layout of the policy.  Results never depend on any of this.
+enum { CP_BRICKS = 0, CP_ZPAIR = 1, CP_ZFAST = 2, CP_XPAIR = 3, CP_N = 4 };
+static size_t layout_budget(const vv_context *c)
+{
+    if (c->layout_budget_bytes) return c->layout_budget_bytes;
+    return std::max<size_t>((size_t)8 << 30, c->alloc_bytes / 2 * 5);
+}
+static bool copy_valid(const vv_context *c, int k) { return k == CP_BRICKS ? c->bricks_valid : k == CP_ZPAIR ? c->zpair_valid : k == CP_ZFAST ? c->zfast_valid : c->xpair_valid; }
+static size_t copy_bytes(const vv_context *c, int k) { return !copy_valid(c, k) ? 0 : k == CP_BRICKS ? c->bricks_bytes : k == CP_ZPAIR ? c->zpair_bytes : k == CP_ZFAST ? c->zfast_bytes : c->xpair_bytes; }
+static void copy_drop(vv_context *c, int k)
+{
+    void **p = k == CP_BRICKS ? &c->d_bricks : k == CP_ZPAIR ? &c->d_zpair : k == CP_ZFAST ? &c->d_zfast : &c->d_xpair;
+    if (*p) (void)hipFree(*p);                       // (hipFree waits for the device: frames still in flight on a caller's stream have finished with it)
+    *p = nullptr;
+    if (k == CP_BRICKS) { c->bricks_valid = false; c->bricks_bytes = 0; } else if (k == CP_ZPAIR) { c->zpair_valid = false; c->zpair_bytes = 0; }
+    else if (k == CP_ZFAST) { c->zfast_valid = false; c->zfast_bytes = 0; } else { c->xpair_valid = false; c->xpair_bytes = 0; }
+}
+// Room for `need` more bytes of copies?  `keep`: bit mask of copies that must stay (the ones the frame being set up samples or builds from).
+static bool make_room(vv_context *c, size_t need, unsigned keep)
+{
+    const size_t budget = layout_budget(c);
+    if (need > budget) return false;
+    for (;;) {
+        size_t used = 0;
+        for (int k = 0; k < CP_N; ++k) used += copy_bytes(c, k);
+        if (used + need <= budget) return true;
+        int victim = -1;
+        for (int k = 0; k < CP_N; ++k)
+            if (copy_valid(c, k) && !(keep & (1u << k)) && (victim < 0 || c->last_used[k] < c->last_used[victim])) victim = k;
+        if (victim < 0) return false;
+        copy_drop(c, victim);
+    }
+}
+
 
 extern "C" {
 
@@ -300,15 +347,26 @@ int vv_prepare_layouts(vv_context *c, int which, void *stream)
 {
     if (!c) return fail(nullptr, VV_ERR_INVALID, "vv_prepare_layouts: NULL context");
     if (!c->d_vol) return fail(c, VV_ERR_NO_VOLUME, "vv_prepare_layouts: no volume loaded");
-    if (which & ~(VV_LAYOUT_BRICKED | VV_LAYOUT_ZPAIR | VV_LAYOUT_ZFAST)) return fail(c, VV_ERR_INVALID, "vv_prepare_layouts: unknown layout bit");
+    if (which & ~(VV_LAYOUT_BRICKED | VV_LAYOUT_ZPAIR | VV_LAYOUT_ZFAST | VV_LAYOUT_POLICY)) return fail(c, VV_ERR_INVALID, "vv_prepare_layouts: unknown layout bit");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = pick_stream(c, stream);
+    const bool pair_ok = c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20);          // (the z-pair / x-pair conditions of vv_render)
+    if (which & VV_LAYOUT_POLICY) {
+        // every copy vv_render's policy can pick for this volume, in the order of what an orbit needs most: oblique views, side views, the pair copies
+        if ((size_t)c->nx * c->ny * c->nz >= (1ull << 21)) which |= VV_LAYOUT_BRICKED | VV_LAYOUT_ZFAST;
+        if (pair_ok) which |= VV_LAYOUT_ZPAIR;
+    }
     int built = 0;
     if (which & VV_LAYOUT_BRICKED) c->bricks_failed = false;       // an explicit request retries after an earlier shortage of HBM
-    if (which & VV_LAYOUT_ZFAST) c->zfast_failed = false;
-    if ((which & VV_LAYOUT_BRICKED) && ensure_bricks(c, st)) built |= VV_LAYOUT_BRICKED;
-    if ((which & VV_LAYOUT_ZPAIR) && ensure_zpair(c, st)) built |= VV_LAYOUT_ZPAIR;
-    if ((which & VV_LAYOUT_ZFAST) && ensure_zfast(c, st)) built |= VV_LAYOUT_ZFAST;
+    if (which & VV_LAYOUT_ZFAST) { c->zfast_failed = false; c->xpair_failed = false; }
+    // (a copy built here counts as just used: the next one must not evict it to make room for itself)
+    if ((which & VV_LAYOUT_BRICKED) && ensure_bricks(c, st)) { built |= VV_LAYOUT_BRICKED; c->last_used[CP_BRICKS] = ++c->frame_no; }
+    if ((which & VV_LAYOUT_ZFAST) && ensure_zfast(c, st)) {
+        built |= VV_LAYOUT_ZFAST; c->last_used[CP_ZFAST] = ++c->frame_no;
+        // side views of unshaded frames take the x-pair copy where front views take the z-pair copy: built with the z-fastest copy it is made from
+        if (pair_ok && ensure_xpair(c, st)) c->last_used[CP_XPAIR] = ++c->frame_no;
+    }
+    if ((which & VV_LAYOUT_ZPAIR) && ensure_zpair(c, st)) { built |= VV_LAYOUT_ZPAIR; c->last_used[CP_ZPAIR] = ++c->frame_no; }
     return built;
 }
 
@@ -316,6 +374,25 @@ int vv_reread_env(vv_context *c)
 {
     if (!c) return VV_ERR_INVALID;
     c->knobs.read();
+    return VV_OK;
+}
+
+int vv_set_layout_policy(vv_context *c, unsigned long long budget_bytes, int build_in_render)
+{
+    if (!c) return fail(nullptr, VV_ERR_INVALID, "vv_set_layout_policy: NULL context");
+    c->layout_budget_bytes = (size_t)budget_bytes;
+    c->build_in_render = build_in_render != 0;
+    return VV_OK;
+}
+
+int vv_layout_state(const vv_context *c, unsigned long long out[8])
+{
+    if (!c || !out) return VV_ERR_INVALID;
+    out[0] = c->d_vol ? c->alloc_bytes : 0;
+    for (int k = 0; k < CP_N; ++k) out[1 + k] = copy_bytes(c, k);
+    out[5] = c->d_vol ? layout_budget(c) : c->layout_budget_bytes;
+    out[6] = c->builds_in_render;
+    out[7] = c->build_in_render ? 1 : 0;
     return VV_OK;
 }
 
@@ -547,6 +624,7 @@ static bool ensure_bricks(vv_context *c, hipStream_t st)
     uint32_t sy = 0, sz64 = 0;
     const size_t bb = brick_copy_bytes(c->vtype, c->nx, c->ny, c->nz, &sy, &sz64);
     size_t free_b = 0, total_b = 0;
+    if (!make_room(c, bb, 1u << CP_BRICKS)) { c->bricks_failed = true; return false; }
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bb + (512ull << 20) || sz64 >= (1u << 24) || sy >= (1u << 24) ||
         hipMalloc(&c->d_bricks, bb + 16) != hipSuccess) {                  // (the sampler multiplies b_sy and b_sz64 as 24-bit values)
         (void)hipGetLastError(); c->d_bricks = nullptr; c->bricks_failed = true;
@@ -568,6 +646,7 @@ static bool ensure_zpair(vv_context *c, hipStream_t st)
     uint32_t rb = 0, sb = 0;
     const size_t zb = zpair_copy_bytes(c->vtype, c->nx, c->ny, c->nz, &rb, &sb);
     size_t free_b = 0, total_b = 0;
+    if (!make_room(c, zb, 1u << CP_ZPAIR)) return false;
     if ((size_t)(c->ny + 1) * ((size_t)c->nx + 1) * 8 >= (1ull << 32) || ((size_t)c->nx + 1) * 8 >= (1u << 24) ||
         (c->vtype == VV_VOXEL_U8 && zb >= (1ull << 32)) ||                // u8 sampler: 32-bit offsets
         hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < zb + (512ull << 20) ||
@@ -598,6 +677,7 @@ static bool ensure_zfast(vv_context *c, hipStream_t st)
     if (row % 1024 == 32 && (rows * row) % 4096 == 0) rows += 1;
     const size_t slice = rows * row, bytes = slice * ((size_t)c->nx + 1) + row + 16;
     size_t free_b = 0, total_b = 0;
+    if (c->ny > 65535 || (c->nz + 31) / 32 > 65535 || !make_room(c, bytes, 1u << CP_ZFAST)) { c->zfast_failed = true; return false; }     // (launch_build_zfast: one grid layer per row)
     if (row >= (1u << 24) || slice >= (1ull << 32) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (512ull << 20) ||
         hipMalloc(&c->d_zfast, bytes) != hipSuccess) {
         (void)hipGetLastError(); c->d_zfast = nullptr; c->zfast_failed = true;
@@ -621,6 +701,7 @@ static bool ensure_xpair(vv_context *c, hipStream_t st)
     uint32_t rb = 0, sb = 0;
     const size_t xb = zpair_copy_bytes(c->vtype, c->nz, c->ny, c->nx, &rb, &sb);
     size_t free_b = 0, total_b = 0;
+    if (!make_room(c, xb, (1u << CP_XPAIR) | (1u << CP_ZFAST))) { c->xpair_failed = true; return false; }
     if ((size_t)(c->ny + 1) * ((size_t)c->nz + 1) * 8 >= (1ull << 32) || ((size_t)c->nz + 1) * 8 >= (1u << 24) ||
         (c->vtype == VV_VOXEL_U8 && xb >= (1ull << 32)) ||                // u8 sampler: 32-bit offsets
         hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < xb + (512ull << 20) ||
@@ -629,7 +710,8 @@ static bool ensure_xpair(vv_context *c, hipStream_t st)
         return false;
     }
     launch_build_xpair(c->vtype, c->d_zfast, c->zf_row, c->zf_slice, c->d_xpair, c->nx, c->ny, c->nz, st);
-    if (hipMemsetAsync((char *)c->d_xpair + xb, 0, 32, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    if (hipGetLastError() != hipSuccess ||
+        hipMemsetAsync((char *)c->d_xpair + xb, 0, 32, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         (void)hipGetLastError(); (void)hipFree(c->d_xpair); c->d_xpair = nullptr; c->xpair_failed = true;
         return false;
     }
@@ -850,8 +932,11 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         use_zfast = az >= 0.97f * sqrtf(ax * ax + ay * ay + az * az) && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
         if (K.zfast >= 0) use_zfast = K.zfast != 0;
     }
-    if (use_zfast) use_zfast = ensure_zfast(c, st);
+    ++c->frame_no;
+    const unsigned long long builds_before = (unsigned long long)c->bricks_valid + c->zpair_valid + c->zfast_valid + c->xpair_valid;
+    if (use_zfast) use_zfast = c->build_in_render ? ensure_zfast(c, st) : c->zfast_valid;
     if (use_zfast) {
+        c->last_used[CP_ZFAST] = c->frame_no;
         A.strips.tile_log2w = 5;
         A.V.zfast = c->d_zfast; A.V.zf_row_bytes = c->zf_row; A.V.zf_slice_bytes = c->zf_slice;
     }
@@ -919,8 +1004,9 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     bool use_bricks = A.strips.tile_log2w == 3 && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
     if (K.bricked >= 0) use_bricks = K.bricked != 0;
     if (use_zfast) use_bricks = false;
-    if (use_bricks) use_bricks = ensure_bricks(c, st);
+    if (use_bricks) use_bricks = c->build_in_render ? ensure_bricks(c, st) : c->bricks_valid;
     if (use_bricks) {
+        c->last_used[CP_BRICKS] = c->frame_no;
         A.V.bricks = c->d_bricks; A.V.b_sy = c->b_sy; A.V.b_sz64 = c->b_sz64;
         // measured (C3 rotated, 1024^3): 2 blocks per CU and 2 samples per trip: 3.64 -> 1.60 ms
         if (!k_unroll) A.unroll = 2;
@@ -937,15 +1023,18 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
                      (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20));
     if (K.zpair >= 0) use_zpair = K.zpair != 0 && !use_bricks;
     if (use_zfast) use_zpair = false;
-    if (use_zpair) use_zpair = ensure_zpair(c, st);
-    if (use_zpair) { A.V.zpair = c->d_zpair; A.V.zp_row_bytes = c->zp_row; A.V.zp_slab_bytes = c->zp_slab; }
+    if (use_zpair) use_zpair = c->build_in_render ? ensure_zpair(c, st) : c->zpair_valid;
+    if (use_zpair) { c->last_used[CP_ZPAIR] = c->frame_no; A.V.zpair = c->d_zpair; A.V.zp_row_bytes = c->zp_row; A.V.zp_slab_bytes = c->zp_slab; }
     // x-pair copy (speed only): the same two-gather form for side views -- the z-pair copy with x and z exchanged, handed to the kernel in the
     // z-pair fields of the view -- under the z-pair copy's conditions (unshaded, u8 or f32 up to 512 MiB).  Follows VV_ZPAIR=0.
     A.xpair = false;
-    if (use_zfast && !shading->phongShading && K.zpair != 0 && (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20)) && ensure_xpair(c, st)) {
-        A.xpair = true;
+    if (use_zfast && !shading->phongShading && K.zpair != 0 && (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20)) &&
+        (c->build_in_render ? ensure_xpair(c, st) : c->xpair_valid)) {
+        A.xpair = true; c->last_used[CP_XPAIR] = c->frame_no;
         A.V.zpair = c->d_xpair; A.V.zp_row_bytes = c->xp_row; A.V.zp_slab_bytes = c->xp_slab;
     }
+    c->builds_in_render += ((unsigned long long)c->bricks_valid + c->zpair_valid + c->zfast_valid + c->xpair_valid > builds_before)
+                           ? ((unsigned long long)c->bricks_valid + c->zpair_valid + c->zfast_valid + c->xpair_valid - builds_before) : 0;
     // Phong kernel: 14.3 KB of LDS per block + this reserve.  Measured (tools/ab_phong.sh): volumes up to
     // 1 GiB like 5 blocks per CU (C2 0.54 -> 0.47 ms against no cap, u8 1024^3 1.88 -> 1.78), the 4 GiB
     // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)

@@ -5,11 +5,23 @@
 //   advanced_slice_kernel kernel.cu:599-644
 //   ellipsoid_kernel      VolumeGenerator::drawEllipsoid, volumegenerator.cpp:31-97,
 //                         n ellipsoids fused into one pass over the volume
+#include <atomic>
 #include "vv_device.h"
 #include "vv_kernels.h"
 #include <cstdlib>
 
 namespace vv {
+
+// Lanes of ONE wave handing data to each other through LDS (ellipsoid_rows_kernel): program order between the store and the other lanes' load,
+// stated to the compiler as a wave-scope release / acquire pair around a wave barrier.  No instruction is emitted for it on gfx950 (LDS operations of
+// a wave are issued and completed in order); it only forbids the compiler to reorder or forward across it.
+__device__ __forceinline__ void vv_wave_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 
 // ---------------------------------------------------------------------------
 // slice view
@@ -452,9 +464,13 @@ void ellipsoid_rows_kernel(uint8_t *__restrict__ out, int nx, int ny, int nz, in
                 // 2 x 16 ballot bits into byte masks
                 const bool own_b = lane == cb, own = lane == ca || own_b;
                 char *slot = patch + (own_b ? 16 : 0);
+                // (the hardware keeps one wave's LDS operations in order; the wave-scope fences + barriers say so to the compiler too: they emit nothing)
                 if (own) *(uint4 *)slot = make_uint4(packed4[0], packed4[1], packed4[2], packed4[3]);
+                vv_wave_lds_order();
                 if (pv) patch[lane] = (char)col4;
+                vv_wave_lds_order();
                 if (own) { const uint4 r = *(const uint4 *)slot; packed4[0] = r.x; packed4[1] = r.y; packed4[2] = r.z; packed4[3] = r.w; }
+                vv_wave_lds_order();                                                   // (the next ellipsoid's owners overwrite the slots)
             }
         }
         if (seg == last_seg) {
@@ -498,8 +514,10 @@ void ellipsoid_rows_kernel(uint8_t *__restrict__ out, int nx, int ny, int nz, in
             const float tsum = cur + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cur), 0x108, 0xf, 0xf, false));
             const uint32_t tb = (uint32_t)__builtin_amdgcn_ballot_w64(tsum < 1.0f);      // else no voxel of the row is inside (ellipsoid_kernel)
             if (lane < 32) wterms[lane] = cur;                                          // (this wave's own reads follow in order)
+            vv_wave_lds_order();
             do_segment(sga, cur, tb & nmask, 0);
             do_segment(sgb, cur, (tb >> 16) & nmask, 16);
+            vv_wave_lds_order();                                                        // (the next pair's terms overwrite wterms)
         }
     }
 }
@@ -545,20 +563,20 @@ void launch_generate_ellipsoids(uint8_t *out, int nx, int ny, int nz, int n,
         // ... with the x tables in LDS when they fit it twice per CU (ellipsoid_rows_kernel)
         const size_t lds = ((size_t)n * G.nx16 + 3 * (size_t)n * G.nch) * sizeof(float) + 16 * 32 + 16 + 16 * 160;      // tables + 32 bytes per wave + the ticket counter + row terms and colours per wave
         // the kernel's dynamic LDS limit is raised once per device (a one-process multi-GPU host, include/volviz_mgpu.h, comes here with each of its devices)
-        static unsigned long long dev_ok = 0ull, dev_bad = 0ull;
+        static std::atomic<unsigned long long> dev_ok{0ull}, dev_bad{0ull};        // (a multi-GPU host may come here from one thread per device)
         int rows_ok = 0;
         {
             int dv = 0;
             if (hipGetDevice(&dv) == hipSuccess && dv >= 0 && dv < 64) {
                 const unsigned long long bit = 1ull << dv;
-                if (!((dev_ok | dev_bad) & bit)) {
+                if (!((dev_ok.load() | dev_bad.load()) & bit)) {
                     const bool ok = hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
                                     hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
                                     hipFuncSetAttribute((const void *)ellipsoid_rows_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
                     (void)hipGetLastError();
-                    (ok ? dev_ok : dev_bad) |= bit;
+                    (ok ? dev_ok : dev_bad).fetch_or(bit);
                 }
-                rows_ok = (dev_ok & bit) ? 1 : 0;
+                rows_ok = (dev_ok.load() & bit) ? 1 : 0;
             }
         }
         const size_t segments = (size_t)ny * nz * (nx / 1024);
@@ -791,7 +809,9 @@ __global__ __launch_bounds__(256) void zfast_kernel(const T *__restrict__ in, ui
 
 void launch_build_zfast(int vtype, const void *vol, uint32_t row_pitch, uint64_t slice_pitch, void *out, uint32_t zf_row_bytes, uint64_t zf_slice_bytes, int nx, int ny, int nz, hipStream_t s)
 {
-    // (grid.z <= 65535: volumes are at most 4096 voxels on a side for the sampler's 24-bit multiplies)
+    // grid.z = ny must stay within the launch limit of 65535 (volumes may have up to 2^24 - 1 rows: vv_load_volume_*); the caller (ensure_zfast) does
+    // not ask for this copy beyond it and the bricked copy serves the view
+    if (ny > 65535 || (nz + 31) / 32 > 65535) return;
     const dim3 grid((unsigned)((nx + 31) / 32), (unsigned)((nz + 31) / 32), (unsigned)ny);
     if (vtype == VV_VOXEL_F32)
         hipLaunchKernelGGL(zfast_kernel<float>, grid, dim3(256), 0, s, (const float *)vol, row_pitch, slice_pitch, (float *)out, zf_row_bytes, zf_slice_bytes, nx, ny, nz);

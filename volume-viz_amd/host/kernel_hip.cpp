@@ -54,6 +54,12 @@ extern "C" void runCuda(int width, int height, struct slice_params slice, struct
 extern "C" void cudaLoadVolume(byte *texels, size_t size, Vector3 dims, float transferFunction[1024], void **)
 {                                                                        // kernel.cu:456-498
     check(vv_load_volume_u8(ctx(), texels, size, (int)dims.x, (int)dims.y, (int)dims.z, transferFunction), "cudaLoadVolume");
+    // The copies of the volume the launch policy can sample (include/volviz.h, "optional second layouts") are built here, at load time, so that no
+    // frame of the paint loop pays for one (cudaMalloc3DArray hides the texture's layout in the reference; this is where its cost belongs).  Within the
+    // context's HBM budget; a copy that does not fit is skipped and vv_render takes the next layout.  Frames never build afterwards.
+    const int rc = vv_prepare_layouts(ctx(), VV_LAYOUT_POLICY, nullptr);
+    if (rc < 0) check(rc, "cudaLoadVolume (vv_prepare_layouts)");
+    check(vv_set_layout_policy(ctx(), 0, 0), "cudaLoadVolume (vv_set_layout_policy)");
 }
 
 void invoke_slice_kernel(float *buffer, BufferParameters bp, SliceParameters sp, canonicalOrientation c, float3 scale)

@@ -25,7 +25,7 @@ SLICE_NONE, SLICE_PLANE, SLICE_PLANE_CUT = -1, 0, 1
 # params.h:46
 HORIZONTAL, SAGITTAL, CORONAL, FREE_FORM = 0, 1, 2, 4
 VOXEL_U8, VOXEL_F32 = 0, 1
-LAYOUT_BRICKED, LAYOUT_ZPAIR, LAYOUT_ZFAST = 1, 2, 4
+LAYOUT_BRICKED, LAYOUT_ZPAIR, LAYOUT_ZFAST, LAYOUT_POLICY = 1, 2, 4, 256
 FILTER_TEX8, FILTER_EXACT = 0, 1
 ERT_REFERENCE, ERT_TRUE = 0, 1
 RAYS_IMAGES, RAYS_ANALYTIC = 0, 1
@@ -79,7 +79,7 @@ EXPORTS = [
     "vv_last_sample_count", "vv_volume_dims", "vv_slice_matrix", "vv_draw_ellipsoid", "vv_debug_counters",
     "vv_first_pass", "vv_cut_plane_canonical", "vv_cut_plane_from_euler", "vv_cut_plane_to_slice_params", "vv_slice_to_bgra",
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
-    "vv_prepare_layouts", "vv_device_bytes", "vv_reread_env",
+    "vv_prepare_layouts", "vv_set_layout_policy", "vv_layout_state", "vv_device_bytes", "vv_reread_env",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
     "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset", "vv_debug_last_launch",
 ]
@@ -146,6 +146,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_reread_env.argtypes = [vp]
     lib.vv_prepare_layouts.argtypes = [vp, i, vp]
     lib.vv_device_bytes.argtypes = [vp, vp]
+    lib.vv_set_layout_policy.argtypes = [vp, C.c_ulonglong, i]
+    lib.vv_layout_state.argtypes = [vp, vp]
     lib.vv_volume_dims.argtypes = [vp, C.POINTER(i * 3), C.POINTER(i)]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -411,11 +413,23 @@ class Context:
         return int(self.lib.vv_last_sample_count(self.h))
 
     def prepare_layouts(self, which: int = 3, stream=None) -> int:
-        """vv_prepare_layouts: build the bricked (1) / z-pair (2) copies now; returns the resident mask."""
+        """vv_prepare_layouts: build the bricked (1) / z-pair (2) / z-fastest (4, with the x-pair copy) copies now, or LAYOUT_POLICY = every copy
+        the launch policy can pick for the loaded volume; returns the resident mask."""
         rc = self.lib.vv_prepare_layouts(self.h, which, stream)
         if rc < 0:
             self._chk(rc)
         return rc
+
+    def set_layout_policy(self, budget_bytes: int = 0, build_in_render: bool = True):
+        """vv_set_layout_policy: HBM budget of the optional copies (0 = default) and whether vv_render may build a missing one."""
+        self._chk(self.lib.vv_set_layout_policy(self.h, int(budget_bytes), int(build_in_render)))
+
+    def layout_state(self) -> dict:
+        """vv_layout_state: resident bytes per layout, the budget, copies built inside vv_render since the load."""
+        out = np.zeros(8, np.uint64)
+        self._chk(self.lib.vv_layout_state(self.h, out.ctypes.data))
+        k = ("linear", "bricked", "zpair", "zfast", "xpair", "budget", "builds_in_render", "build_in_render")
+        return dict(zip(k, (int(v) for v in out)))
 
     def device_bytes(self):
         """vv_device_bytes: [linear volume, bricked copy, z-pair + z-fastest copies, tables + scratch]."""
