@@ -696,10 +696,13 @@ def test_zfast_side_views(ctx, monkeypatch):
     # built up front on request
     vol = rng.integers(0, 256, size=(9, 10, 12), dtype=np.uint8).astype(np.float32) / np.float32(255)
     ctx.load_volume(vol, tf)
-    assert ctx.prepare_layouts(vv.LAYOUT_ZFAST) == vv.LAYOUT_ZFAST and ctx.device_bytes()[2] == (12 + 1) * 10 * 9 * 4 + 9 * 4 + 16
+    # (... together with the x-pair copy, which unshaded side views of such a volume sample: include/volviz.h)
+    assert ctx.prepare_layouts(vv.LAYOUT_ZFAST) == vv.LAYOUT_ZFAST
+    st = ctx.layout_state()
+    assert st["zfast"] == (12 + 1) * 10 * 9 * 4 + 9 * 4 + 16 and st["xpair"] > 0 and ctx.device_bytes()[2] == st["zfast"] + st["xpair"]
     ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)
     assert ctx.device_bytes()[2] == 0
-    assert ctx.prepare_layouts(vv.LAYOUT_ZFAST) == vv.LAYOUT_ZFAST and ctx.device_bytes()[2] == (4 + 1) * 4 * 4 + 4 + 16
+    assert ctx.prepare_layouts(vv.LAYOUT_ZFAST) == vv.LAYOUT_ZFAST and ctx.layout_state()["zfast"] == (4 + 1) * 4 * 4 + 4 + 16
 
 
 def test_zfast_default_policy(ctx, monkeypatch):
@@ -1281,7 +1284,7 @@ def test_touched_lines_instrument(ctx, monkeypatch):
     """vv_render_options::touched_lines (the roofline's line-granular byte count): a 32^3 f32 volume has rows of exactly one 128-byte line;
     a frame whose samples cover every voxel must mark every line of the volume (+ at most the zero padding's rows that the weight-0 corners
     of edge samples read), the `issued` set contains the `compulsory` one, both layouts agree on the frame, and the bricked copy's lines
-    (320-byte bricks) are counted from that copy's own addresses."""
+    are counted from that copy's own addresses."""
     import torch
     n = 32
     vol = O.noise_u8(n, n, n, 3).astype(np.float32) / np.float32(255)
@@ -1308,10 +1311,10 @@ def test_touched_lines_instrument(ctx, monkeypatch):
         assert np.all(got[1] >= got[0]), env                                   # issued contains compulsory
         counts[env["VV_BRICKED"]] = int(got[0].sum())
         assert ctx.last_launch()["layout"] == (2 if env["VV_BRICKED"] == "1" else 0)
+        brick_total_lines = ctx.layout_state()["bricked"] // 128
     vol_lines = n * n * n * 4 // 128                                           # 1024: one line per row
     assert vol_lines <= counts["0"] <= vol_lines + n + 4, counts                # every row of the volume + at most the first padding slice's rows (weight-0 corners)
-    brick_lines = (n // 4) ** 3 * 320 // 128                                    # 1280
-    assert brick_lines <= counts["1"] <= brick_lines + 2 * (n // 4) * (n // 4 + 1) * 3 + 64, counts      # every brick + at most the clamped extra layers in y and z
+    assert 0.7 * brick_total_lines <= counts["1"] <= brick_total_lines, (counts, brick_total_lines)   # every brick of the volume; of the clamped extra layers in y and z only what edge samples read
 
 
 def test_layout_residency_policy(monkeypatch):

@@ -669,8 +669,9 @@ size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_
     size_t row = nbx * brick;                                     // brick sizes are multiples of 64
     // a row of bricks that is a multiple of 4 KiB gets 64 bytes more (same cache-channel effect as the
     // linear pitch, smaller: rotated C3 -1...-4 %, + Phong -4 %); VV_BRICK_PAD=<bytes, multiple of 64> / 0 overrides
-    size_t pad = (vtype == VV_VOXEL_F32 && row % 4096 == 0) ? 64 : 0;      // u8 bricks (one line each): +7 % with it
+    size_t pad = (vtype == VV_VOXEL_F32 && row % 4096 == 0) ? (BrickGeom<VV_VOXEL_F32>::brick % 128 == 0 ? 128 : 64) : 0;      // u8 bricks (one line each): +7 % with it
     if (const char *e = getenv("VV_BRICK_PAD")) { int t = atoi(e); if (t >= 0 && t <= 4096 && t % 64 == 0) pad = (size_t)t; }
+    if (nx >= (1 << 20)) { if (sy) *sy = 0xFFFFFFFFu; if (sz64) *sz64 = 0xFFFFFFFFu; return ~(size_t)0 >> 1; }      // (brick_x_offset's range; ensure_bricks then takes the linear path)
     row += pad;
     const size_t layer = nby * row;
     if (sy) *sy = (uint32_t)row;

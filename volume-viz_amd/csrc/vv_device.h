@@ -73,8 +73,32 @@ template <int VOXEL> struct BrickGeom;
 #ifndef VV_BRICK_ZLOG2
 #define VV_BRICK_ZLOG2 2          // f32 bricks are (1 << VV_BRICK_ZLOG2) voxels deep in z (experiment knob: 3 = 4x4x8 bricks, profiles/r04_brick_shape.txt)
 #endif
+#ifndef VV_BRICK_X7
+#define VV_BRICK_X7 1             // f32 bricks are 7 voxels + 1 halo voxel long in x: rows of 32 bytes, a z-layer of a brick (4 rows) is exactly one 128-byte line
+#endif
+#if VV_BRICK_X7
+template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t xlog2 = 0, bx = 7, halo = 1, row = 32,
+                                             zlog2 = VV_BRICK_ZLOG2, bz = 1u << zlog2, rows = 4 * bz, brick = rows * row; };
+#else
 template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t xlog2 = VV_BRICK_XLOG2, bx = 1u << xlog2, halo = VV_BRICK_HALO, row = (bx + halo) * 4,
                                              zlog2 = VV_BRICK_ZLOG2, bz = 1u << zlog2, rows = 4 * bz, brick = rows * row; };
+#endif
+// voxel x -> byte offset of its brick in a row of bricks + of the voxel in its brick row.  Bricks of 7: x / 7 through the float reciprocal rounded up
+// (0x3E124925 > 1/7): fl(x * r) >= x / 7 for every x, and it stays below the next integer while x / 7 * 2^-23 < 1/7, i.e. for every x a volume can have
+// here (brick_copy_bytes refuses nx >= 2^20)
+template <int VOXEL>
+__device__ __forceinline__ uint32_t brick_x_offset(uint32_t ix)
+{
+    using G = BrickGeom<VOXEL>;
+    if constexpr (VOXEL == VV_VOXEL_F32 && G::bx == 7) {
+        const uint32_t q = (uint32_t)((float)ix * 0.142857149f);
+        return __umul24(q, G::brick - 28u) + (ix << 2);                 // q * brick + (ix - 7 q) * 4
+    } else if constexpr (VOXEL == VV_VOXEL_F32) {
+        return __umul24(ix >> G::xlog2, G::brick) + ((ix & (G::bx - 1u)) << 2);
+    } else {
+        return (ix >> 2) * G::brick;
+    }
+}
 template <> struct BrickGeom<VV_VOXEL_U8>  { static constexpr uint32_t xlog2 = 2, bx = 4, halo = 1, row = 8, zlog2 = 2, bz = 4, rows = 16, brick = 128; };
 enum { LAYOUT_LINEAR = 0, LAYOUT_LINEAR_BIG = 1, LAYOUT_BRICKED = 2, LAYOUT_ZPAIR = 3, LAYOUT_ZFAST = 4 };
 
@@ -370,7 +394,7 @@ __device__ __forceinline__ void fetch_corners(const VolumeView &V, float px, flo
         const char *L0 = (const char *)V.bricks + ((uint64_t)m0 << 6);
         const char *L1 = (const char *)V.bricks + ((uint64_t)m1 << 6);
         if constexpr (VOXEL == VV_VOXEL_F32) {
-            const uint32_t ox = __umul24(ix >> G::xlog2, G::brick) + ((ix & (G::bx - 1u)) << 2);
+            const uint32_t ox = brick_x_offset<VOXEL>(ix);
             const uint32_t o0 = ox + oy0, o1 = ox + oy1;
             if constexpr (G::halo != 0) {
                 C.a = *(const float2u *)(L0 + (o0 + zi0)); C.b = *(const float2u *)(L0 + (o1 + zi0));
@@ -594,7 +618,7 @@ __device__ __forceinline__ void brick_offsets(const VolumeView &V, uint32_t ix, 
     const uint32_t oy1 = oy0 + (ya == 3u ? V.b_sy - 3u * G::row : G::row);
     const uint64_t m0 = (uint64_t)(iz >> G::zlog2) * V.b_sz64, m1 = m0 + (za == G::bz - 1u ? V.b_sz64 : 0u);
     const uint32_t zi0 = za * 4u * G::row, zi1 = za == G::bz - 1u ? 0u : zi0 + 4u * G::row;
-    const uint32_t ox = VOXEL == VV_VOXEL_F32 ? (ix >> G::xlog2) * G::brick + ((ix & (G::bx - 1u)) << 2) : (ix >> 2) * G::brick;
+    const uint32_t ox = brick_x_offset<VOXEL>(ix);
     a[0] = (m0 << 6) + ox + oy0 + zi0; a[1] = (m0 << 6) + ox + oy1 + zi0;
     a[2] = (m1 << 6) + ox + oy0 + zi1; a[3] = (m1 << 6) + ox + oy1 + zi1;
 }
