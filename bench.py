@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--filter", default="tex8", choices=["tex8", "exact"])
     ap.add_argument("--ert", default="reference", choices=["reference", "true"])
     ap.add_argument("--phong", action="store_true", help="Phong-shaded path (diagnostic; C3 is unshaded)")
+    ap.add_argument("--rays", default="analytic", choices=["analytic", "images"], help="images: march from two 3x first-pass images resident in HBM, the runCuda-shaped call (diagnostic)")
     ap.add_argument("--frame-of", type=int, default=0, help="render the frame/step an N-GPU run would use (check aid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -222,6 +223,12 @@ def main():
     if args.orbit:
         th, ph = (float(v) for v in args.orbit.split(","))
         cam = vv.Camera.orbit(4.0, np.radians(th), np.radians(ph))
+    main_rays = None
+    if args.rays == "images":
+        _iw, _ih = 3 * W, 3 * H
+        _dfront = torch.empty(_ih * _iw * 4, dtype=torch.uint8, device=dev); _dback = torch.empty_like(_dfront)
+        ctx.first_pass_device(_iw, _ih, cam, _dfront.data_ptr(), _dback.data_ptr(), stream)
+        main_rays = vv.device_image_rays(_dfront.data_ptr(), _dback.data_ptr(), _iw, _ih, hint=cam)
     step = 1.0 / steps
     base = dict(step=step, filter=vv.FILTER_TEX8 if args.filter == "tex8" else vv.FILTER_EXACT,
                 ert_mode=vv.ERT_REFERENCE if args.ert == "reference" else vv.ERT_TRUE,
@@ -249,7 +256,7 @@ def main():
 
     def one_frame(o, b=0):
         G.finish(b)
-        ctx.render_device(W, H, cam, G.frames[b].data_ptr(), options=o, stream=stream, phong=args.phong)
+        ctx.render_device(W, H, cam, G.frames[b].data_ptr(), options=o, stream=stream, phong=args.phong, rays=main_rays)
         submit(b)
 
     # ---- untimed instrumented pass: executed samples + bricks touched (byte model) ----
@@ -282,7 +289,22 @@ def main():
             torch.cuda.synchronize()
             res.append(int(np.unpackbits(bm.cpu().numpy().view(np.uint8)).sum()) * 128 + 4 * Wx * (rows_owned if c is ctx else Hx) + 4096)
             del bm
-        return {"compulsory_line_bytes": res[0], "issued_line_bytes": res[1]}
+        out_l = {"compulsory_line_bytes": res[0], "issued_line_bytes": res[1]}
+        # ... and per thread block: distinct (block, line) pairs of every gather issued = what the frame fetches if blocks share nothing and a
+        # block never loses a line it still needs.  traffic above this figure is re-fetching inside blocks; this figure above `issued` is the
+        # overlap between blocks' footprints (partial lines at tile edges, apron rays of the Phong kernel)
+        if os.environ.get("VV_BENCH_BLOCK_LINES", "1") != "0":
+            lg = 28
+            tab = torch.zeros(1 << lg, dtype=torch.int64, device=dev)
+            io = vv.make_options(touched_block_lines=tab.data_ptr(), touched_block_lines_log2=lg, touched_lines_all=True, **ob)
+            c.render_device(Wx, Hx, camera, frame.data_ptr() if c is ctx else scratch_frame(Wx, Hx).data_ptr(), options=io, stream=stream, phong=phong, rays=rays)
+            torch.cuda.synchronize()
+            npairs = int((tab != 0).sum().item())
+            del tab
+            out_l["block_line_bytes"] = npairs * 128 + 4 * Wx * (rows_owned if c is ctx else Hx) + 4096
+            if npairs > (1 << lg) * 0.6:
+                out_l["block_line_note"] = "hash set more than 60 % full: a lower bound"
+        return out_l
 
     _scratch = {}
 
@@ -291,9 +313,11 @@ def main():
             _scratch[(Wx, Hx)] = torch.zeros(Hx * Wx, dtype=torch.int32, device=dev)
         return _scratch[(Wx, Hx)]
 
-    samples, bytes_rank = instrumented(cam, args.phong)
+    samples, bytes_rank = instrumented(cam, args.phong, main_rays)
+    if main_rays is not None:
+        bytes_rank += 8 * W * rows_owned                   # the two texels each pixel's ray is read from
     try:
-        lines_main = line_bytes(cam, args.phong) if world == 1 else None
+        lines_main = line_bytes(cam, args.phong, main_rays) if world == 1 else None
     except Exception as e:                      # an instrument beside the metric: never at its cost
         lines_main = {"error": f"{type(e).__name__}: {e}"}
     if os.environ.get("VV_STATS"):      # developer statistics from a counters-only frame (no brick marking)
@@ -316,17 +340,17 @@ def main():
     cold_ms = None
     if world == 1:
         for _ in range(args.warmup):
-            ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong)
+            ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong, rays=main_rays)
         ce = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         torch.cuda.synchronize()
         for k in range(args.steps):
             ce[k][0].record()
-            ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong)
+            ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong, rays=main_rays)
             ce[k][1].record()
         torch.cuda.synchronize()
         cold_ms = float(np.mean([a.elapsed_time(b) for a, b in ce]))
     for _ in range(spinup):
-        ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong)
+        ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong, rays=main_rays)
     torch.cuda.synchronize()
 
     # ---- warm-up, then the timed region ----
@@ -344,7 +368,7 @@ def main():
         b = k & 1
         G.finish(b)
         ev[k][0].record()
-        ctx.render_device(W, H, cam, G.frames[b].data_ptr(), options=opts, stream=stream, phong=args.phong)
+        ctx.render_device(W, H, cam, G.frames[b].data_ptr(), options=opts, stream=stream, phong=args.phong, rays=main_rays)
         ev[k][1].record()
         submit(b)
     G.drain()                                        # every frame is complete on rank 0 inside the timed region
@@ -389,7 +413,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = samples_all * args.steps / elapsed / 1e6
     achieved = bytes_rank / (kern_ms * 1e-3)
-    key = f"{args.config}-{args.volume}-{args.tf}-{args.view}{'-phong' if args.phong else ''}-n{world}"
+    key = f"{args.config}-{args.volume}-{args.tf}-{args.view}{'-phong' if args.phong else ''}{'-u8' if args.voxel == 'u8' else ''}{'-images' if main_rays is not None else ''}-n{world}"
     traffic, traffic_note = (None, "diagnostic camera") if args.orbit else measured_traffic(key)
     if traffic is None and traffic_note is None:
         traffic_note = f"no PMC passes committed for {key}"
@@ -437,7 +461,8 @@ def main():
     # Not part of `value`: the other shipped march kernels on the same workload, each with its own algorithmic bytes
     # (instrumented, untimed pass) and roofline fraction: the camera off the memory axis (SURVEY 8d's second camera:
     # vv_render samples the bricked copy) and the Phong-shaded frame (march_phong_kernel).
-    if world == 1 and args.config == "c3" and args.view == "a" and not args.orbit and not args.phong and not os.environ.get("VV_BENCH_NO_EXTRA"):
+    plain_c3 = world == 1 and args.config == "c3" and args.view == "a" and not args.orbit and not args.phong and args.voxel == "f32" and main_rays is None and not args.size
+    if plain_c3 and not os.environ.get("VV_BENCH_NO_EXTRA"):
         def timed(camera, phong, reps=20, rays=None):
             for _ in range(60):           # steady state on the other layout / kernel (see the spin-up above)
                 ctx.render_device(W, H, camera, frame.data_ptr(), options=opts, stream=stream, phong=phong, rays=rays)
@@ -450,6 +475,47 @@ def main():
             return e0.elapsed_time(e1) / reps
 
         cam_b = vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5)
+        # What a frame costs when the copy of the volume its view samples is not resident yet (vv_render then builds it: hipMalloc + one kernel over
+        # the volume + a stream synchronisation), and what loading with vv_prepare_layouts(VV_LAYOUT_POLICY) -- the mirror's cudaLoadVolume does that --
+        # costs instead.  Wall clock around the call + a device synchronisation.
+        try:
+            torch.cuda.synchronize()
+            st0 = ctx.layout_state()
+            t0 = time.perf_counter()
+            ctx.render_device(W, H, cam_b, frame.data_ptr(), options=opts, stream=stream)
+            torch.cuda.synchronize()
+            first_b = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            ctx.prepare_layouts(vv.LAYOUT_POLICY)
+            torch.cuda.synchronize()
+            prep = (time.perf_counter() - t0) * 1e3
+            ctx.set_layout_policy(0, False)                    # from here on no frame builds anything
+            st1 = ctx.layout_state()
+            out["residency"] = {"what": "device memory of the C3 context: linear volume + the optional copies (include/volviz.h); budget = what the copies together may take",
+                                "bytes": {k: st1[k] for k in ("linear", "bricked", "zpair", "zfast", "xpair", "budget")},
+                                "resident_before_the_first_oblique_frame": {k: st0[k] for k in ("bricked", "zfast")},
+                                "first_frame_ms_oblique_view_copy_not_resident": round(first_b, 3),
+                                "prepare_remaining_layouts_ms": round(prep, 3),
+                                "note": "a host that calls vv_prepare_layouts(VV_LAYOUT_POLICY) at load (the mirror's cudaLoadVolume / PaintLoop::loadVolume do) never sees the first figure"}
+        except Exception as e:
+            out["residency"] = {"error": f"{type(e).__name__}: {e}"}
+        # The view-robust number: C3 over a fixed orbit of 12 cameras on the reference's orbit (glwidget.cpp:435-445: radius 4, up = +y), polar angles
+        # 30 / 60 / 90 degrees x azimuths -90 (the headline's axis), -54, 0 (side view), 36 degrees.
+        try:
+            per = []
+            for th in (30.0, 60.0, 90.0):
+                for ph in (-90.0, -54.0, 0.0, 36.0):
+                    co = vv.Camera.orbit(4.0, np.radians(th), np.radians(ph))
+                    ns_o, by_o = instrumented(co, False)
+                    ms_o = timed(co, False, reps=15)
+                    per.append({"theta": th, "phi": ph, "ms": round(ms_o, 4), "Msamples": round(ns_o / 1e6, 1), "frac": round(by_o / (ms_o * 1e-3) / HBM_PEAK, 4),
+                                "layout": ctx.last_launch()["layout"]})
+            out["orbit"] = {"what": "C3 over 12 cameras of the reference's orbit (radius 4; theta 30 / 60 / 90 deg x phi -90 / -54 / 0 / 36 deg); each with its own algorithmic bytes; layout 1 = linear, 2 = bricked, 4 = z-fastest",
+                            "mean_ms": round(float(np.mean([q["ms"] for q in per])), 4), "worst_ms": max(q["ms"] for q in per),
+                            "mean_frac": round(float(np.mean([q["frac"] for q in per])), 4), "worst_frac": min(q["frac"] for q in per), "per_camera": per,
+                            "builds_inside_frames": ctx.layout_state()["builds_in_render"] - st1["builds_in_render"]}
+        except Exception as e:
+            out["orbit"] = {"error": f"{type(e).__name__}: {e}"}
         for name, camera, phong, what, tkey in (
                 ("rotated_view", cam_b, False, "camera on the orbit r=4, theta=60 deg, phi=36 deg: march_kernel on the bricked copy", "c3-noise-ramp-b-n1"),
                 ("side_view", vv.Camera(origin=(-4.0, 0.0, 0.0)), False, "camera on the -x axis (screen x along the volume's z): march_kernel on the z-fastest copy", "c3-noise-ramp-side-n1"),
@@ -492,7 +558,7 @@ def main():
                                   "note": "the 8-bit end points of the first-pass contract (firstpass.frag:4) bunch neighbouring rays on a 1/255 grid: that, not the image fetch, is the difference to analytic rays",
                                   "launch": {k: ll[k] for k in ("tile_log2w", "blk_log2w", "unroll", "lds_reserve", "layout", "view_known")},
                                   "roofline": {"bound": "hbm", "achieved": round(by_i / (ms_i * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                               "frac": round(by_i / (ms_i * 1e-3) / HBM_PEAK, 4), "traffic": None, "algorithmic_bytes_per_launch": int(by_i)}}
+                                               "frac": round(by_i / (ms_i * 1e-3) / HBM_PEAK, 4), "traffic": measured_traffic("c3-noise-ramp-a-images-n1")[0], "algorithmic_bytes_per_launch": int(by_i)}}
             del dfront, dback
         except Exception as e:
             out["images_path"] = {"error": f"{type(e).__name__}: {e}"}
@@ -528,7 +594,7 @@ def main():
             return None, f"no profiles/pmc_sub.json ({type(e).__name__})"
 
     def sub_records():
-        if not (world == 1 and args.config == "c3" and args.view == "a" and not args.orbit and not args.phong and not os.environ.get("VV_BENCH_NO_EXTRA")):
+        if not (plain_c3 and not os.environ.get("VV_BENCH_NO_EXTRA")):
             return
         cam0 = vv.Camera()
         # -- C2 (BASELINE.json configs[1]): 256^3 f32, 1280x720, step 1/256, grey table (Head).  Lives in the caches: not HBM-bound;
@@ -577,10 +643,17 @@ def main():
             ou = vv.make_options(step=1.0 / 512)
             msu, fru = sub_timed(cu, W, H, cam0, ou, False, 20, warm=60)
             nsu, byu = sub_instrumented(cu, W, H, cam0, 1.0 / 512, False, nu, 1, fru)
+            pmu, pnoteu = pmc_sub("u8")
             out["u8_volume"] = {"what": "C3's frame and step on the same noise volume stored as u8, the reference's voxel type (1 GiB): march_kernel on the z-pair copy",
                                 "ms_per_frame": round(msu, 4), "value": round(nsu / msu / 1e3, 1), "unit": "Msamples/s", "executed_samples_per_frame": int(nsu), "launch": cu.last_launch(),
-                                "roofline": {"bound": "hbm", "achieved": round(byu / (msu * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                             "frac": round(byu / (msu * 1e-3) / HBM_PEAK, 4), "traffic": None, "algorithmic_bytes_per_launch": int(byu)}}
+                                # 0.9 GB in 0.6 ms is 1.5 TB/s: this frame is not bound by HBM.  It issues vector instructions most of the time (the bytes of a sample are unpacked
+                                # and converted in the VALU): the bound is VALU issue, reported as the fraction of issue slots used (committed PMC pass, tools/pmc_sub.py)
+                                "roofline": {"bound": "valu", "achieved": None if pmu is None else pmu.get("valu_issue_fraction"), "peak": 1.0, "unit": "fraction of VALU issue cycles",
+                                             "frac": None if pmu is None else pmu.get("valu_issue_fraction"),
+                                             "wave_wait_fraction": None if pmu is None else pmu.get("wave_wait_fraction"),
+                                             "hbm_frac": round(byu / (msu * 1e-3) / HBM_PEAK, 4), "traffic": measured_traffic("c3-noise-ramp-a-u8-n1")[0],
+                                             "algorithmic_bytes_per_launch": int(byu),
+                                             "pmc_source": "committed PMC pass (profiles/pmc_sub.json, tools/pmc_sub.py)" + (f"; {pnoteu}" if pnoteu else "")}}
             cu.close(); del u8v, fru
         except Exception as e:
             out["u8_volume"] = {"error": f"{type(e).__name__}: {e}"}
@@ -641,7 +714,8 @@ def main():
                          "upload_seconds": round(up, 3), "upload_GB_per_s": round(n5 ** 3 / up / 1e9, 2),
                          "upload_note": "includes this script's single-threaded host memcpy of every 128 MiB slab into the one pinned buffer (about two thirds of it); the library's streamer alone: tools/time_upload.py",
                          "roofline": {"bound": "hbm", "achieved": round(by5 / (ms5 * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                      "frac": round(by5 / (ms5 * 1e-3) / HBM_PEAK, 4), "traffic": None, "algorithmic_bytes_per_launch": int(by5)}}
+                                      "frac": round(by5 / (ms5 * 1e-3) / HBM_PEAK, 4), "traffic": measured_traffic("c5-noise-ramp-a-phong-n1")[0], "algorithmic_bytes_per_launch": int(by5)},
+                         "device_bytes": c5.layout_state()}
             c5.close(); del fr5
         except Exception as e:
             out["c5"] = {"error": f"{type(e).__name__}: {e}"}

@@ -155,6 +155,11 @@ typedef struct vv_render_options {
     uint32_t *touched_lines;
     unsigned long long touched_line_bits;   /* size of touched_lines in bits */
     int      touched_lines_all;
+    /* ... and per block: a zero-initialised device hash set of 2^log2 64-bit words that receives one entry per (thread block, line) pair
+     * under the same rule (count the non-zero words afterwards): the bytes the frame fetches if blocks share nothing.  Size it at
+     * >= 2 x the pairs expected.  NULL = off. */
+    unsigned long long *touched_block_lines;
+    int      touched_block_lines_log2;
 } vv_render_options;
 
 /* ---- lifecycle ---------------------------------------------------------------- */

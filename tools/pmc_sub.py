@@ -32,7 +32,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     import bench
     entries, detail = {}, {}
-    for key, extra, want in (("c2", ["--config", "c2", "--tf", "head"], "march_kernel"), ("c2-phong", ["--config", "c2", "--tf", "head", "--phong"], "march_phong_kernel")):
+    for key, extra, want in (("c2", ["--config", "c2", "--tf", "head"], "march_kernel"), ("c2-phong", ["--config", "c2", "--tf", "head", "--phong"], "march_phong_kernel"),
+                             ("u8", ["--voxel", "u8"], "march_kernel")):
         acc = {}
         name = None
         for i, p in enumerate(PASSES):

@@ -15,7 +15,8 @@ os.environ.setdefault("TMPDIR", "/tmp")
 os.environ["VV_BENCH_NO_EXTRA"] = "1"
 OUT = os.path.join(REPO, "gpurun_out", "pmc_traffic")
 CONFIGS = {"c3-noise-ramp-a-n1": ["--view", "a"], "c3-noise-ramp-b-n1": ["--view", "b"], "c3-noise-ramp-a-phong-n1": ["--view", "a", "--phong"],
-           "c3-noise-ramp-side-n1": ["--orbit", "90,180"]}
+           "c3-noise-ramp-side-n1": ["--orbit", "90,180"], "c3-noise-ramp-a-u8-n1": ["--voxel", "u8"], "c3-noise-ramp-a-images-n1": ["--rays", "images"],
+           "c5-noise-ramp-a-phong-n1": ["--config", "c5"]}
 N = 1024
 
 

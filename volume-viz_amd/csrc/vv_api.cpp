@@ -805,7 +805,10 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         A.tex8 = opts->filter != VV_FILTER_EXACT;
         if (!(opts->slab_row_begin == 0 && opts->slab_row_end == 0)) { rb = opts->slab_row_begin; re = opts->slab_row_end; }
         if (opts->shard_count > 1) { s_count = opts->shard_count; s_index = opts->shard_index; s_band = opts->shard_band; }
-        A.instr = opts->count_samples != 0 || opts->touched_bricks != nullptr || opts->touched_lines != nullptr;
+        A.instr = opts->count_samples != 0 || opts->touched_bricks != nullptr || opts->touched_lines != nullptr || opts->touched_block_lines != nullptr;
+        if (opts->touched_block_lines && (opts->touched_block_lines_log2 < 10 || opts->touched_block_lines_log2 > 34))
+            return fail(c, VV_ERR_INVALID, "vv_render: touched_block_lines_log2 must lie in [10, 34]");
+        A.I.pairs = opts->touched_block_lines; A.I.pairs_log2 = (uint32_t)opts->touched_block_lines_log2;
         A.I.bricks = opts->touched_bricks;
         A.I.lines = opts->touched_lines; A.I.line_bits = opts->touched_lines ? opts->touched_line_bits : 0; A.I.lines_all = opts->touched_lines_all;
     }

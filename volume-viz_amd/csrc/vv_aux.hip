@@ -680,7 +680,7 @@ size_t brick_copy_bytes(int vtype, int nx, int ny, int nz, uint32_t *sy, uint32_
 }
 
 // one thread per stored element: E elements per brick row (BX voxels + halo [+ padding]), 4 BZ rows per brick (y fastest, then z)
-template <typename T, int E, int BX, int BZ>
+template <typename T, int E, int BX, int BZ, int BRICK_ELEMS>
 __global__ __launch_bounds__(256) void brick_kernel(const T *__restrict__ in, size_t row_pitch, size_t slice_pitch, T *__restrict__ out,
                                                     int nx, int ny, int nz, size_t nbx, size_t nby, size_t total,
                                                     size_t brow /* elements per row of bricks */, size_t blayer /* per layer */)
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void brick_kernel(const T *__restrict__ in, si
         const size_t b = t / (E * R);
         const size_t bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
         const int x = min((int)bx * BX + e, nx - 1), y = min((int)by * 4 + (r & 3), ny - 1), z = min((int)bz * BZ + (r >> 2), nz - 1);
-        out[bz * blayer + by * brow + bx * (size_t)(E * R) + (size_t)(r * E + e)] =
+        out[bz * blayer + by * brow + bx * (size_t)BRICK_ELEMS + (size_t)(r * E + e)] =
             e <= BX ? ((const T *)((const char *)in + (size_t)z * slice_pitch + (size_t)y * row_pitch))[x] : T(0);
     }
 }
@@ -713,9 +713,9 @@ void launch_build_bricks(int vtype, const void *linear, size_t row_pitch, size_t
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (vtype == VV_VOXEL_F32)
-        hipLaunchKernelGGL((brick_kernel<float, FBX + FH, FBX, FBZ>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, row_pitch, slice_pitch, (float *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
+        hipLaunchKernelGGL((brick_kernel<float, FBX + FH, FBX, FBZ, BrickGeom<VV_VOXEL_F32>::brick / 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)linear, row_pitch, slice_pitch, (float *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
     else
-        hipLaunchKernelGGL((brick_kernel<uint8_t, 8, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, row_pitch, slice_pitch, (uint8_t *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
+        hipLaunchKernelGGL((brick_kernel<uint8_t, 8, 4, 4, 128>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint8_t *)linear, row_pitch, slice_pitch, (uint8_t *)bricks, nx, ny, nz, nbx, nby, total, brow, blayer);
 }
 
 // ---------------------------------------------------------------------------

@@ -74,11 +74,18 @@ template <int VOXEL> struct BrickGeom;
 #define VV_BRICK_ZLOG2 2          // f32 bricks are (1 << VV_BRICK_ZLOG2) voxels deep in z (experiment knob: 3 = 4x4x8 bricks, profiles/r04_brick_shape.txt)
 #endif
 #ifndef VV_BRICK_X7
-#define VV_BRICK_X7 1             // f32 bricks are 7 voxels + 1 halo voxel long in x: rows of 32 bytes, a z-layer of a brick (4 rows) is exactly one 128-byte line
+// 1: f32 bricks 7 voxels + 1 halo voxel long in x: rows of 32 bytes, a z-layer of a brick (4 rows) is exactly one 128-byte line, bricks of 512 bytes.
+// Measured in round 5 (profiles/r05_brick_aligned.txt) and NOT used: 25-40 % slower than the 320-byte bricks on oblique views, cache-resident volumes
+// included, at any brick stride or depth: with aligned layers the z and z + 1 rows of a sample are always two lines (L1 misses + 40 %), whereas the four
+// gathers of a sample span 108 bytes of a 320-byte brick and mostly hit one line.
+#define VV_BRICK_X7 0
+#endif
+#ifndef VV_BRICK_EXTRA
+#define VV_BRICK_EXTRA 0          // unused bytes behind each f32 brick (experiment knob: brick strides that are not a power of two)
 #endif
 #if VV_BRICK_X7
 template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t xlog2 = 0, bx = 7, halo = 1, row = 32,
-                                             zlog2 = VV_BRICK_ZLOG2, bz = 1u << zlog2, rows = 4 * bz, brick = rows * row; };
+                                             zlog2 = VV_BRICK_ZLOG2, bz = 1u << zlog2, rows = 4 * bz, brick = rows * row + VV_BRICK_EXTRA; };
 #else
 template <> struct BrickGeom<VV_VOXEL_F32> { static constexpr uint32_t xlog2 = VV_BRICK_XLOG2, bx = 1u << xlog2, halo = VV_BRICK_HALO, row = (bx + halo) * 4,
                                              zlog2 = VV_BRICK_ZLOG2, bz = 1u << zlog2, rows = 4 * bz, brick = rows * row; };
@@ -598,13 +605,26 @@ struct InstrArgs {
     uint64_t  line_bits;     // size of `lines` in bits (lines beyond it are not marked)
     int       lines_all;     // 0: lines of executed in-volume samples only (what has to be fetched at line granularity);
                              // 1: lines of every gather the kernel issues, idle lanes and out-of-volume samples included
+    unsigned long long *pairs;   // open-addressing hash set of (block, line) pairs, 2^pairs_log2 zero-initialised words, or NULL: the lines each
+    uint32_t  pairs_log2;        // block touches, counted per block (what the frame fetches if nothing is shared between blocks)
 };
 __device__ __forceinline__ void mark_line_range(const InstrArgs &I, uint64_t off, uint32_t bytes)
 {
     for (uint64_t l = off >> 7; l <= (off + bytes - 1u) >> 7; ++l) {
-        if (l >= I.line_bits) continue;
-        const uint32_t bit = 1u << (l & 31);
-        if (!(I.lines[l >> 5] & bit)) atomicOr(&I.lines[l >> 5], bit);
+        if (I.lines && l < I.line_bits) {
+            const uint32_t bit = 1u << (l & 31);
+            if (!(I.lines[l >> 5] & bit)) atomicOr(&I.lines[l >> 5], bit);
+        }
+        if (I.pairs) {
+            const unsigned long long key = ((unsigned long long)(blockIdx.x + 1u) << 36) | (l & 0xFFFFFFFFFull);
+            const unsigned long long mask = (1ull << I.pairs_log2) - 1ull;
+            unsigned long long h = (key * 0x9E3779B97F4A7C15ull) >> (64u - I.pairs_log2);
+            for (int probe = 0; probe < (1 << 14); ++probe, h = (h + 1ull) & mask) {          // (bounded: a full table drops the pair instead of spinning)
+                const unsigned long long seen = I.pairs[h];
+                if (seen == key) break;
+                if (seen == 0ull) { const unsigned long long old = atomicCAS(&I.pairs[h], 0ull, key); if (old == 0ull || old == key) break; }
+            }
+        }
     }
 }
 

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                         executed++;
                         if (I.bricks && inv) mark_bricks(I.bricks, V, tx[u], ty[u], tz[u]);
                     }
-                    if (I.lines && (I.lines_all || (live && inv))) mark_sample_lines<VOXEL, TEX8>(I, V, tx[u], ty[u], tz[u]);
+                    if ((I.lines || I.pairs) && (I.lines_all || (live && inv))) mark_sample_lines<VOXEL, TEX8>(I, V, tx[u], ty[u], tz[u]);
                 }
                 {
 #pragma clang fp contract(off)
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
                         executed++;
                         if (I.bricks && inv) mark_bricks(I.bricks, V, tx[u], ty[u], tz[u]);
                     }
-                    if (I.lines && (I.lines_all || (live && inv))) mark_sample_lines<VOXEL, TEX8>(I, V, tx[u], ty[u], tz[u]);
+                    if ((I.lines || I.pairs) && (I.lines_all || (live && inv))) mark_sample_lines<VOXEL, TEX8>(I, V, tx[u], ty[u], tz[u]);
                 }
                 {
                     // :268-270 + blend :107-118, predicated: with bf == 0 the sums are unchanged
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
                             // (entries 1..30 of a compositing ray are the samples it can execute; entries 0 / 31 and the apron threads' are gradient-only)
                             const bool need = mine && i >= 1 && i <= 30 && bounds_check(tx_[u], ty_[u], tz_[u]);
                             if (I.bricks && need) mark_bricks(I.bricks, V, tx_[u], ty_[u], tz_[u]);
-                            if (I.lines && (I.lines_all || need)) mark_sample_lines<VOXEL, TEX8>(I, V, tx_[u], ty_[u], tz_[u]);
+                            if ((I.lines || I.pairs) && (I.lines_all || need)) mark_sample_lines<VOXEL, TEX8>(I, V, tx_[u], ty_[u], tz_[u]);
                         }
                     }
                 };

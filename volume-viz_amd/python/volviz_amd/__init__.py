@@ -67,7 +67,8 @@ class vv_render_options(C.Structure):
                 ("ert_mode", C.c_int), ("slab_row_begin", C.c_int), ("slab_row_end", C.c_int),
                 ("shard_band", C.c_int), ("shard_count", C.c_int), ("shard_index", C.c_int),
                 ("count_samples", C.c_int), ("touched_bricks", C.c_void_p),
-                ("touched_lines", C.c_void_p), ("touched_line_bits", C.c_ulonglong), ("touched_lines_all", C.c_int)]
+                ("touched_lines", C.c_void_p), ("touched_line_bits", C.c_ulonglong), ("touched_lines_all", C.c_int),
+                ("touched_block_lines", C.c_void_p), ("touched_block_lines_log2", C.c_int)]
 
 
 EXPORTS = [
@@ -263,7 +264,7 @@ def make_slice_params(slice_type: int = SLICE_NONE, point=(0.5, 0.5, 0.5), norma
 
 def make_options(step=None, ert_threshold=0.0, filter=FILTER_TEX8, ert_mode=ERT_REFERENCE,
                  slab_rows=(0, 0), shard=None, count_samples=False, touched_bricks=0, touched_lines=0, touched_line_bits=0,
-                 touched_lines_all=False) -> vv_render_options:
+                 touched_lines_all=False, touched_block_lines=0, touched_block_lines_log2=0) -> vv_render_options:
     o = vv_render_options()
     if step is not None:
         s = [step] * 3 if np.isscalar(step) else list(step)
@@ -279,6 +280,8 @@ def make_options(step=None, ert_threshold=0.0, filter=FILTER_TEX8, ert_mode=ERT_
     o.touched_lines = touched_lines
     o.touched_line_bits = touched_line_bits
     o.touched_lines_all = int(touched_lines_all)
+    o.touched_block_lines = touched_block_lines
+    o.touched_block_lines_log2 = touched_block_lines_log2
     return o
 
 
