@@ -2,10 +2,10 @@
 # GPU box: the profile set of round 5 under the DRIVER's bench protocol (python3 bench.py --steps 20 --warmup 5) -> gpurun_out/<tag>/ ; copy the summaries into profiles/.
 # New against tools/r04_profiles.sh: the Phong frame and C5 get kernel-trace runs of their own (one kernel, one workload per CSV: each bench number is one line of one file),
 # and the PMC passes carry TCC_EA0_RDREQ_DRAM beside TCC_EA0_RDREQ.
-#   usage: tools/r05_profiles.sh <tag> [part ...]     parts: bench trace pmc phong c5 sub traffic (default: all)
+#   usage: tools/r05_profiles.sh <tag> [part ...]     parts: bench trace pmc phong pmcphong c5 sub traffic (default: all)
 set -u
 TAG=${1:-r05prof}; shift || true
-PARTS=${*:-bench trace pmc phong c5 sub traffic}
+PARTS=${*:-bench trace pmc phong pmcphong c5 sub traffic}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
@@ -36,8 +36,19 @@ if has pmc; then
   done
   python3 tools/pmc_summary.py $OUT "big::march_kernel<-1, 1, true, false, false" > $OUT/pmc_march_kernel.txt
   python3 tools/pmc_summary.py $OUT "brick::march_kernel<-1, 1, true, false, false" > $OUT/pmc_march_kernel_viewb_bricked.txt
-  python3 tools/pmc_summary.py $OUT "big::march_phong_kernel<-1, 1, true, false>" > $OUT/pmc_march_phong_kernel.txt
   python3 tools/pmc_summary.py $OUT "zfast::march_kernel<-1, 1, true, false, false" > $OUT/pmc_march_kernel_side_zfast.txt
+fi
+if has pmcphong; then
+  # the Phong frame alone (in the full bench run the same kernel name also marches C5's frames): its own passes, its own directory
+  mkdir -p $OUT/phong; i=0
+  for pass in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_HIT_sum TCC_MISS_sum" \
+              "TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
+              "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES" \
+              "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+    i=$((i+1))
+    VV_BENCH_NO_EXTRA=1 rocprofv3 --pmc $pass --output-format csv -d $OUT/phong/pmc_$i -o pmc -- python3 bench.py --phong --steps 20 --warmup 5 --no-cpu-baseline > $OUT/phong/pmc_$i.json 2> $OUT/phong/pmc_$i.err || echo "phong pmc pass $i failed"
+  done
+  python3 tools/pmc_summary.py $OUT/phong "big::march_phong_kernel<-1, 1, true, false>" > $OUT/pmc_march_phong_kernel.txt
 fi
 if has sub; then python3 tools/pmc_sub.py > $OUT/pmc_sub.log 2>&1 || echo "pmc_sub failed"; cp gpurun_out/pmc_sub.json $OUT/ 2>/dev/null; fi
 if has traffic; then python3 tools/pmc_traffic.py > $OUT/pmc_traffic.log 2>&1 || echo "pmc_traffic failed"; cp gpurun_out/pmc_traffic.json $OUT/ 2>/dev/null; fi
