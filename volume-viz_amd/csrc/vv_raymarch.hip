@@ -147,16 +147,8 @@ __device__ __forceinline__ void stage_tf(float4 *lds_tf, const float4 *__restric
     for (int i = threadIdx.x; i < 256; i += blockDim.x) lds_tf[i] = tf[i];
     __syncthreads();
 }
-// Channel-planar copy of the table: entry idx of channel c sits in LDS bank idx % 32, so the
-// data-dependent look-up of a wave spreads over all banks (the float4 layout hits 8 of 32).
-__device__ __forceinline__ void stage_tf_planar(float *lds_tf, const float4 *__restrict__ tf)
-{
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        float4 e = tf[i];
-        lds_tf[i] = e.x; lds_tf[256 + i] = e.y; lds_tf[512 + i] = e.z; lds_tf[768 + i] = e.w;
-    }
-    __syncthreads();
-}
+// march_kernel keeps the table channel-planar in LDS: entry idx of channel c sits in bank idx % 32, so the data-dependent look-up of a wave
+// spreads over all banks (the float4 layout hits 8 of 32).
 
 // ---------------------------------------------------------------------------
 // march_kernel: no Phong.  blockDim = 256 = 4 waves; a block owns a 32x8 pixel strip (64x4 / 128x2 with StripMap::blk_log2w 6 / 7), each
@@ -196,7 +188,9 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
     const int x = (tile_x << bl) + (wx << tw) + (lane & ((1 << tw) - 1));
     const int y = M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * (256 >> bl) + (wy << th) + (lane >> tw);
     if (strip >= M.n_strips) return;                       // block-uniform, before any barrier
-    stage_tf_planar(lds_tf, tf);
+    // The table entry this thread stages is loaded now and parked in LDS behind the ray set-up (which needs no table): its latency hides behind
+    // the set-up's divisions instead of standing in front of them (blockDim.x == 256 == entries: every launch of this kernel).  C3 -0.6 %, C2 -1.1 %.
+    const float4 tf_entry = tf[threadIdx.x];
     // pixels the reference never writes: column W-1 / row H-1 (W,H >= 2)
     const int xmax = P.W >= 2 ? P.W - 2 : 0, ymax = P.H >= 2 ? P.H - 2 : 0;
     const bool in_frame = x <= xmax && y <= ymax && row_owned(P, y);
@@ -226,6 +220,10 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         }
     }
     if (!alive) { r.upper = -1.f; r.dist0 = 0.f; r.sstep = 1.f; r.origin = mk3(0, 0, 0); r.dir = r.origin; r.sdir = r.origin; }
+    // (Round 5 also let a block none of whose rays meets the volume -- 62 % of C3's blocks -- leave right here, before the table wait: 0 ... +1 % on
+    //  every workload, +1-2 % on the rotated view.  Empty blocks are cheap enough as they are; not kept.  profiles/EXPERIMENTS.md part A5.)
+    lds_tf[threadIdx.x] = tf_entry.x; lds_tf[256 + threadIdx.x] = tf_entry.y; lds_tf[512 + threadIdx.x] = tf_entry.z; lds_tf[768 + threadIdx.x] = tf_entry.w;
+    __syncthreads();
 
     float dist = r.dist0;
     bool ert = false;
