@@ -1377,3 +1377,36 @@ def test_layout_residency_policy(monkeypatch):
         for k, cam in views.items():
             assert np.array_equal(c.render(W, H, cam, options=o), want[k]), k
             assert c.last_launch()["layout"] in (0, 1)
+
+
+def test_frames_enqueued_back_to_back():
+    """Frames enqueued back to back on caller streams -- every frame another camera (other slab radii in the rad pre-pass's buffer), alternating frame
+    sizes (the scratch buffers are re-allocated) and alternating streams, nothing synchronised in between -- must each equal the oracle's: what a
+    renderer that never waits for a frame sees.  An image ray source between analytic ones."""
+    import torch
+    vol = O.noise_u8(48, 40, 44, 21).astype(np.float32) / np.float32(255)
+    tf = vv.transfer_preset(vv.TF_ENGINE)
+    dev = torch.device("cuda", 0)
+    cams = [vv.Camera.orbit(r, th, ph) for r, th, ph in ((4.0, 1.2, -1.5), (2.5, 0.7, 0.4), (3.0, 2.0, 2.5), (1.6, 1.5, -0.3), (5.0, 0.4, 1.0), (2.2, 1.1, 3.0), (3.5, 1.9, -2.2))]
+    sizes = [(160, 120), (97, 143), (160, 120), (57, 29), (200, 90), (97, 143), (160, 120)]
+    o = vv.make_options(step=1 / 64)
+    want = [O.render(vol, tf, W, H, cam, options=o, fill=0x5A)[0] for cam, (W, H) in zip(cams, sizes)]
+    with vv.Context(0) as c:
+        c.load_volume(vol, tf)
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        for rnd in range(2):
+            bufs = [torch.full((H, W, 4), 0x5A, dtype=torch.uint8, device=dev) for (W, H) in sizes]
+            torch.cuda.synchronize()
+            for k, (cam, (W, H)) in enumerate(zip(cams, sizes)):
+                if rnd:                                     # alternating streams: the caller orders its own streams (frames share the context's scratch)
+                    streams[k & 1].wait_stream(streams[(k & 1) ^ 1])
+                c.render_device(W, H, cam, bufs[k].data_ptr(), options=o, stream=vv.stream_handle(streams[k & 1] if rnd else streams[0]))
+            torch.cuda.synchronize()
+            for k, b in enumerate(bufs):
+                assert np.array_equal(b.cpu().numpy(), want[k]), f"frame {k} (round {rnd})"
+        W, H = sizes[0]
+        front, back = c.first_pass(3 * W, 3 * H, cams[1])
+        got_i = c.render(W, H, cams[1], rays=vv.image_rays(front, back), options=o, fill=0x5A)
+        want_i, _ = O.render(vol, tf, W, H, cams[1], rays=vv.image_rays(front, back), options=o, fill=0x5A)
+        assert np.array_equal(got_i, want_i)
+        assert np.array_equal(c.render(W, H, cams[0], options=o, fill=0x5A), want[0])

@@ -23,14 +23,14 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, zfast = -1, force_big = 0;
-    int block_w = -1, tail = -1, rad_async = -1;
+    int block_w = -1, tail = -1;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
     {
         tile_log2w = geti("VV_TILE_LOG2W", -1); xcd_band = geti("VV_XCD_BAND", -1); unroll = geti("VV_UNROLL", -1);
         lds_reserve = geti("VV_LDS_RESERVE", -1); lds_reserve_phong = geti("VV_LDS_RESERVE_PHONG", -1);
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
-        block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1); rad_async = geti("VV_RAD_ASYNC", -1);
+        block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1);
         zfast = geti("VV_ZFAST", -1); force_big = getenv("VV_FORCE_BIG") != nullptr;
     }
 };
@@ -60,10 +60,6 @@ struct vv_context {
     bool tf_alpha_unit = false;          // every opacity of the table lies in [0, 1]: accumulated opacity never decreases
     // scratch
     float *d_rad = nullptr; size_t rad_cap = 0;
-    // rad pre-pass of frame k on a side stream beside the march of frame k-1 (analytic rays: it reads nothing but the frame's parameters):
-    // two radius buffers in turn, `rad_done[b]` = rad_kernel has filled buffer b, `rad_read[b]` = the march that read buffer b has finished
-    hipStream_t rad_stream = nullptr; float *d_rad2[2] = {nullptr, nullptr}; size_t rad2_cap[2] = {0, 0};
-    hipEvent_t rad_done[2] = {nullptr, nullptr}, rad_read[2] = {nullptr, nullptr}; bool rad_read_valid[2] = {false, false}; int rad_idx = 0;
     uint8_t *d_frame = nullptr; size_t frame_cap = 0;
     uint8_t *d_img = nullptr; size_t img_cap = 0;
     float *d_slice = nullptr; size_t slice_cap = 0;
@@ -260,12 +256,6 @@ int vv_shutdown(vv_context *c)
     drop_bricks(c);
     if (c->d_tf) hipFree(c->d_tf);
     if (c->d_rad) hipFree(c->d_rad);
-    for (int b = 0; b < 2; ++b) {
-        if (c->d_rad2[b]) hipFree(c->d_rad2[b]);
-        if (c->rad_done[b]) hipEventDestroy(c->rad_done[b]);
-        if (c->rad_read[b]) hipEventDestroy(c->rad_read[b]);
-    }
-    if (c->rad_stream) hipStreamDestroy(c->rad_stream);
     if (c->d_frame) hipFree(c->d_frame);
     if (c->d_img) hipFree(c->d_img);
     if (c->d_slice) hipFree(c->d_slice);
@@ -412,7 +402,7 @@ int vv_device_bytes(const vv_context *c, unsigned long long out[4])
     out[0] = c->d_vol ? c->alloc_bytes : 0;
     out[1] = c->bricks_valid ? c->bricks_bytes : 0;
     out[2] = (c->zpair_valid ? c->zpair_bytes : 0) + (c->zfast_valid ? c->zfast_bytes : 0) + (c->xpair_valid ? c->xpair_bytes : 0);
-    out[3] = c->rad_cap + c->rad2_cap[0] + c->rad2_cap[1] + c->frame_cap + c->img_cap + c->slice_cap + 4096 + 8 * sizeof(unsigned long long);
+    out[3] = c->rad_cap + c->frame_cap + c->img_cap + c->slice_cap + 4096 + 8 * sizeof(unsigned long long);
     return VV_OK;
 }
 
@@ -1091,38 +1081,13 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         //  cache-resident volumes want -- 1000^3 f32: 1.884 -> 1.817 ms, tools/ab_env.sh VV_FORCE_BIG=1)
         if (A.xpair) launch_raymarch_xpair(A, st); else if (A.V.zfast) launch_raymarch_zfast(A, st); else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); } else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big || beyond_caches) launch_raymarch_big(A, st); else launch_raymarch(A, st);
     } else if (A.strips.n_strips > 0) {
-        // The rad pre-pass (blockMin per slab: 14 us on C3, a grid of one wave per slab) reads only the frame's parameters when the rays are analytic, so it
-        // does not have to queue behind the previous frame's march: it runs on a side stream into one of two buffers, and the march waits for its event.  A
-        // renderer that enqueues frame after frame (bench.py, a paint loop on a stream) gets the pre-pass and one launch gap off its critical path: C3
-        // frame to frame -1.5 ... -2 %.  A single synchronous frame costs the same as before.  Image ray sources (the pre-pass reads the images, which the
-        // caller's stream may still be writing) keep the in-order launch.  VV_RAD_ASYNC=0 / 1 overrides.
-        int side = -1;
-        bool rad_async = rays->mode == VV_RAYS_ANALYTIC && W >= 2 && H >= 2;
-        if (K.rad_async >= 0) rad_async = rad_async && K.rad_async != 0;
-        if (rad_async) {
-            const int b = c->rad_idx ^= 1;
-            bool ok = true;
-            if (!c->rad_stream) ok = hipStreamCreateWithFlags(&c->rad_stream, hipStreamNonBlocking) == hipSuccess;
-            if (ok && !c->rad_done[b]) ok = hipEventCreateWithFlags(&c->rad_done[b], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->rad_read[b], hipEventDisableTiming) == hipSuccess;
-            if (ok) ok = ensure(c, (void **)&c->d_rad2[b], &c->rad2_cap[b], (size_t)P.nbx * P.nby * sizeof(float)) == VV_OK;
-            if (ok && c->rad_read_valid[b]) ok = hipStreamWaitEvent(c->rad_stream, c->rad_read[b], 0) == hipSuccess;     // the march that read this buffer two frames ago
-            if (ok) {
-                A.rad = c->d_rad2[b]; A.rad_out = c->d_rad2[b];
-                launch_rad(A, c->rad_stream);
-                ok = hipGetLastError() == hipSuccess && hipEventRecord(c->rad_done[b], c->rad_stream) == hipSuccess && hipStreamWaitEvent(st, c->rad_done[b], 0) == hipSuccess;
-                if (ok) side = b;
-                else { (void)hipStreamSynchronize(c->rad_stream); A.rad = c->d_rad; A.rad_out = c->d_rad; }                 // (whatever was enqueued there is done before the buffer is touched again)
-            }
-            (void)hipGetLastError();
-        }
-        if (side < 0 && W >= 2 && H >= 2) launch_rad(A, st);
+        if (W >= 2 && H >= 2) launch_rad(A, st);
         if (A.xpair) launch_raymarch_xpair(A, st);
         else if (A.V.zfast) launch_raymarch_zfast(A, st);
         else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); }
         else if (A.V.zpair) launch_raymarch_zpair(A, st);
         else if (A.V.big) launch_raymarch_big(A, st);
         else launch_raymarch(A, st);
-        if (side >= 0) c->rad_read_valid[side] = hipEventRecord(c->rad_read[side], st) == hipSuccess;
     }
     HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, hipGetLastError());
