@@ -55,6 +55,7 @@ struct vv_context {
     size_t layout_budget_bytes = 0; bool build_in_render = true;
     unsigned long long frame_no = 0, last_used[4] = {0, 0, 0, 0};          // CP_BRICKS, CP_ZPAIR, CP_ZFAST, CP_XPAIR
     unsigned long long builds_in_render = 0;                                  // copies built inside vv_render since the volume was loaded
+    float last_density = 1e9f;                                                // what the launch policy took the last frame's sampling density to be
     // transfer function
     float4 *d_tf = nullptr; bool tf_gray = false; bool have_tf = false;
     bool tf_alpha_unit = false;          // every opacity of the table lies in [0, 1]: accumulated opacity never decreases
@@ -763,6 +764,154 @@ static int camera_basis(vv_context *c, FrameParams &P, const camera_params *cam,
 }
 
 
+} // extern "C"
+
+// ---- launch policy of vv_render (speed only: the pixels never depend on anything decided here) -----------------------------------------------
+// From what is known about the view (`have_basis`: P.side holds the screen x direction in volume space; `density`: voxels of volume per sample, 1e9 =
+// unknown) it picks the layout the frame samples (building a missing copy when the context allows it), the wave tile and block shape, the samples in
+// flight per lane and the blocks per CU, and fills MarchArgs accordingly.  Every threshold below carries the measurement it comes from; the VV_* knobs
+// override single decisions for A/Bs.  Returns whether the volume is beyond the caches (the callers pick the kernel build by it).
+static bool choose_launch(vv_context *c, MarchArgs &A, const camera_params *cam, const vv_ray_source *rays, const shading_params *shading,
+                          bool have_basis, float density, int H, hipStream_t st)
+{
+    FrameParams &P = A.P;
+    A.V = view_of(c); A.V_type = c->vtype;
+    // Wave tile shape (speed only): memory is contiguous along the volume's x axis.  When the
+    // screen x direction maps (almost) onto it, a 32x2 tile lets the 32 lanes of a row read one
+    // or two cache lines (measured C3, view along z: 1.6 ms vs 2.1 ms for 8x8); otherwise the
+    // compact 8x8 tile touches the fewest lines.  VV_TILE_LOG2W overrides (3, 4 or 5).
+    A.strips.tile_log2w = 3;
+    if (have_basis) {
+        const float ax = fabsf(P.side[0]) , ay = fabsf(P.side[1]), az = fabsf(P.side[2]);
+        if (ax >= 0.97f * sqrtf(ax * ax + ay * ay + az * az)) A.strips.tile_log2w = 5;
+    }
+    const vv_knobs &K = c->knobs;
+    // z-fastest copy (speed only): when the screen x direction maps onto the volume's z axis (side views) the same 32 x 2 tile reads whole
+    // lines of a copy whose rows run along z -- the front view's kernel instead of the bricked copy's (C3 1.33 -> 1.0 ms, C2 0.223 -> 0.186,
+    // profiles/r04_side_view.txt).  Both voxel types, both kernels, every volume the bricked copy would serve; built on first use if HBM has
+    // room (one more copy of the volume).  VV_ZFAST=0/1 overrides.
+    bool use_zfast = false;
+    if (have_basis && A.strips.tile_log2w == 3) {
+        const float ax = fabsf(P.side[0]) , ay = fabsf(P.side[1]), az = fabsf(P.side[2]);
+        use_zfast = az >= 0.97f * sqrtf(ax * ax + ay * ay + az * az) && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
+        if (K.zfast >= 0) use_zfast = K.zfast != 0;
+    }
+    ++c->frame_no;
+    const unsigned long long builds_before = (unsigned long long)c->bricks_valid + c->zpair_valid + c->zfast_valid + c->xpair_valid;
+    if (use_zfast) use_zfast = c->build_in_render ? ensure_zfast(c, st) : c->zfast_valid;
+    if (use_zfast) {
+        c->last_used[CP_ZFAST] = c->frame_no;
+        A.strips.tile_log2w = 5;
+        A.V.zfast = c->d_zfast; A.V.zf_row_bytes = c->zf_row; A.V.zf_slice_bytes = c->zf_slice;
+    }
+    if (K.tile_log2w >= 3 && K.tile_log2w <= 5 && !use_zfast) A.strips.tile_log2w = K.tile_log2w;
+    // Occupancy cap + gathers in flight (speed only; measured on MI355X, profiles/EXPERIMENTS.md part B section 4):
+    //   volume beyond the caches (> 1 GiB), aligned view : 2 blocks per CU, 3 samples per trip
+    //   volume beyond the caches, rotated, linear layout : 1 block  per CU, 3 samples per trip
+    //   smaller volumes                                  : 4 blocks per CU, 3 (aligned) / 2 samples per trip
+    //   bricked copy (below)                             : 2 / 4 blocks per CU, 2 samples per trip
+    // LDS per block = 4 KB table + reserve; 160 KB per CU.  VV_LDS_RESERVE / VV_UNROLL override.
+    // XCD-aware block order: XCD k renders strips k, k+8, ... (each a full-width row of tiles), so
+    // the tiles that share volume cache lines share an L2 (measured: -4 % on every workload)
+    A.strips.xcd_band = 1;
+    if (K.xcd_band >= 0 && K.xcd_band <= 64) A.strips.xcd_band = K.xcd_band;
+    const bool beyond_caches = c->vol_bytes > (1ull << 30);
+    // Sampling density: voxels of volume per sample = (voxels per step) x (voxels per pixel)^2 at the
+    // cube centre.  Sparse rays (C3 at 1080p: 4.9) reuse little of a cache line and want few waves on a CU's
+    // L1; the denser frames of the multi-GPU configurations (2716x1528: 2.5, 3840x2160: 1.2, and 0.6 at
+    // step 1/1024) want more: the whole 3840x2160 / 1024-step frame takes 3.51 ms with 2 blocks per CU and
+    // 2.71 ms with 4 (tools/sweep.sh --frame-of 8; bricked copy 4.71 -> 3.34 ms, Phong 9.0 -> 7.9 ms).
+    if ((rays->mode == VV_RAYS_ANALYTIC || image_source_has_hint(rays)) && have_basis && H > 0) {
+        const float dist = vlen_h(cam->origin[0], cam->origin[1], cam->origin[2]);
+        const float vpw = cbrtf(((float)c->nx / (2.f * P.scale[0])) * ((float)c->ny / (2.f * P.scale[1])) * ((float)c->nz / (2.f * P.scale[2])));
+        const float px_vox = 2.f * P.tan_half_y * dist / (float)H * vpw;
+        const float step_vox = fmaxf(P.step[0] * c->nx, fmaxf(P.step[1] * c->ny, P.step[2] * c->nz));
+        if (std::isfinite(px_vox) && std::isfinite(step_vox) && px_vox > 0.f && step_vox > 0.f) density = step_vox * px_vox * px_vox;
+    }
+    const int big_reserve = density > 3.5f ? 76000 : (density > 1.8f ? 49000 : 36000);   // 2 / 3 / 4 blocks per CU
+    // 3 samples per trip along the memory axis (A/B with repeats on MI355X: C3 -1.6 %, C2 -5.7 %, 512^3 -10 %,
+    // u8 1024^3 -6.5 %; 4 per trip is no better), 2 on the bricked copy (3 there: +3.5 %)
+    A.unroll = (A.strips.tile_log2w == 5 || beyond_caches) ? 3 : 2;
+    // (re-swept with tools/ab_reserve.sh at the end of round 1: 4 blocks per CU for volumes up to 1 GiB)
+    A.lds_reserve = !beyond_caches ? 36000 : (A.strips.tile_log2w == 5 ? big_reserve : 155000);
+    // Block shape (speed only).  32 x 2 wave tiles: stacked (32 x 8 pixels), 2 x 2 (64 x 4) or side by side (128 x 2): the partial lines two x-adjacent wave
+    // tiles share are then fetched within one block; strips get lower.  8 x 8 wave tiles: side by side (32 x 8), 2 x 2 (16 x 16) or stacked (8 x 32).  VV_BLOCK_W=8...128.
+    //   measured (tools/ab_env.sh, profiles/r03_block_shape.txt): 64 x 4: C3 -2.4 % (EA bytes 1.474 -> 1.364 x algorithmic), u8 1024^3 -1.3 %, tilted views -1.7 %, but
+    //   +4.5 % on C2, +1 % on C1 / 512^3 and +0.5 % on the dense frames of the multi-GPU configurations: used for sparse frames of volumes beyond the caches.
+    //   16 x 16: a strip 16 pixels high re-reads fewer brick layers of its neighbours (which run on other XCDs): rotated C3 -2 % (EA bytes 2.00 -> 1.81 x), C2 -5.5 %,
+    //   C1 -6.5 %, other orbits -2 ... -4 %, 512^3 and the 3840 x 2160 frame -0.5 %: used for every frame with 8 x 8 tiles.
+    A.strips.blk_log2w = 5;
+    A.strips.tail_batch = K.tail == 0 ? 0 : 1;
+    const int rows_px_8 = A.strips.n_strips * 8;              // (the shard's pixel rows as strips of 8)
+    int block_w = A.strips.tile_log2w == 3 ? 16 : ((A.strips.tile_log2w == 5 && c->vol_bytes >= (1ull << 30) && density > 3.5f) ? 64 : 32);      // (>=: u8 1024^3 -2 %, tools/policy_sweep.sh)
+    if (K.block_w >= 8 && K.block_w <= 128 && (K.block_w & (K.block_w - 1)) == 0) block_w = K.block_w;
+    {
+        int lw = 3; while ((1 << lw) < block_w) ++lw;
+        const int h = 256 >> lw;                               // strip height in pixels
+        if (lw != 5 && lw >= A.strips.tile_log2w && h >= (64 >> A.strips.tile_log2w)) {     // (a block is at least one wave tile wide and high)
+            A.strips.blk_log2w = lw;
+            // rows past the end of a band or of the range belong to nobody or to another rank: not owned (row_owned), their lanes stay idle
+            if (A.strips.strips_per_band < (1 << 26)) {
+                const int band_px = A.strips.strips_per_band * 8, spb = (band_px + h - 1) / h;
+                A.strips.n_strips = (rows_px_8 / band_px) * spb; A.strips.strips_per_band = spb;
+            } else A.strips.n_strips = (rows_px_8 + h - 1) / h;
+        }
+    }
+    const bool k_unroll = K.unroll >= 1 && K.unroll <= 3, k_reserve = K.lds_reserve >= 0 && K.lds_reserve <= 155 * 1024;
+    if (k_unroll) A.unroll = K.unroll;
+    if (k_reserve) A.lds_reserve = K.lds_reserve;
+    // Bricked copy (speed only): off the memory axis the linear layout costs one cache line per lane
+    // and gather; 4x4x4 bricks keep a wave's footprint in a few dozen lines.  both voxel types, both kernels;
+    // built on first use if HBM has room (1.25x an f32 volume, 2x a u8 volume).  VV_BRICKED=0/1 overrides the policy.
+    // Measured: 1024^3 rotated 3.85 -> 1.65 ms (f32), 3.17 -> 0.99 ms (u8); C2 (256^3) -19 %, C1 (128^3) -9 %;
+    // only volumes far below the frame's sampling density lose (64^3 at 1080p, step 1/512: +10 %).
+    bool use_bricks = A.strips.tile_log2w == 3 && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
+    if (K.bricked >= 0) use_bricks = K.bricked != 0;
+    if (use_zfast) use_bricks = false;
+    if (use_bricks) use_bricks = c->build_in_render ? ensure_bricks(c, st) : c->bricks_valid;
+    if (use_bricks) {
+        c->last_used[CP_BRICKS] = c->frame_no;
+        A.V.bricks = c->d_bricks; A.V.b_sy = c->b_sy; A.V.b_sz64 = c->b_sz64;
+        // measured (C3 rotated, 1024^3): 2 blocks per CU and 2 samples per trip: 3.64 -> 1.60 ms
+        if (!k_unroll) A.unroll = 2;
+        if (!k_reserve) A.lds_reserve = beyond_caches ? big_reserve : 36000;
+    }
+    // z-pair copy (speed only): along the memory axis the four corners (x..x+1, z..z+1) of a row come
+    // from one gather (16 bytes for f32, 4 for u8), so a sample costs 2 gathers instead of 4 (f32) or 8
+    // aligned dwords (u8).  2x the volume in HBM.  Measured on MI355X, unshaded frames:
+    //   f32: -7 % on C1/C2, -10 % on 256^3 at C3's frame, -3 % on 512^3, but +6 % on 768^3 and +20 % on
+    //        1024^3 (rays of different z phase stop sharing slices in L2): used up to 512 MiB;
+    //   u8 : -8 % (256^3), -12 % (512^3), -4 % (1024^3): used whenever the copy stays below 4 GiB;
+    //   Phong path: 0...-3 %: not used.                                  VV_ZPAIR=0/1 overrides.
+    bool use_zpair = !use_bricks && A.strips.tile_log2w == 5 && !shading->phongShading &&
+                     (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20));
+    if (K.zpair >= 0) use_zpair = K.zpair != 0 && !use_bricks;
+    if (use_zfast) use_zpair = false;
+    if (use_zpair) use_zpair = c->build_in_render ? ensure_zpair(c, st) : c->zpair_valid;
+    if (use_zpair) { c->last_used[CP_ZPAIR] = c->frame_no; A.V.zpair = c->d_zpair; A.V.zp_row_bytes = c->zp_row; A.V.zp_slab_bytes = c->zp_slab; }
+    // x-pair copy (speed only): the same two-gather form for side views -- the z-pair copy with x and z exchanged, handed to the kernel in the
+    // z-pair fields of the view -- under the z-pair copy's conditions (unshaded, u8 or f32 up to 512 MiB).  Follows VV_ZPAIR=0.
+    A.xpair = false;
+    if (use_zfast && !shading->phongShading && K.zpair != 0 && (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20)) &&
+        (c->build_in_render ? ensure_xpair(c, st) : c->xpair_valid)) {
+        A.xpair = true; c->last_used[CP_XPAIR] = c->frame_no;
+        A.V.zpair = c->d_xpair; A.V.zp_row_bytes = c->xp_row; A.V.zp_slab_bytes = c->xp_slab;
+    }
+    c->builds_in_render += ((unsigned long long)c->bricks_valid + c->zpair_valid + c->zfast_valid + c->xpair_valid > builds_before)
+                           ? ((unsigned long long)c->bricks_valid + c->zpair_valid + c->zfast_valid + c->xpair_valid - builds_before) : 0;
+    // Phong kernel: 14.3 KB of LDS per block + this reserve.  Measured (tools/ab_phong.sh): volumes up to
+    // 1 GiB like 5 blocks per CU (C2 0.54 -> 0.47 ms against no cap, u8 1024^3 1.88 -> 1.78), the 4 GiB
+    // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)
+    // (re-swept with the depth-limited refresh, tools/ab_phong_reserve.sh: C3 1.97 ms with 3, 4 or 5 blocks, 2.22 with 2; the
+    // bricked copy likes 5: rotated C3 + Phong 2.25 -> 2.13 ms; C5 5.95 ms with 2, 6.25 with 3, 6.55 with 5)
+    A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f && !use_bricks) ? 30000 : 13000);
+    if (K.lds_reserve_phong >= 0 && K.lds_reserve_phong <= 146 * 1024) A.lds_reserve_phong = K.lds_reserve_phong;
+    c->last_density = density;
+    return beyond_caches;
+}
+
+extern "C" {
+
 int vv_render(vv_context *c, int W, int H, const slice_params *slice, const camera_params *cam,
               const shading_params *shading, const vv_ray_source *rays, const vv_render_options *opts,
               uint8_t *rgba_out, int out_on_device, void *stream)
@@ -914,137 +1063,8 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
             }
         }
     }
-    A.V = view_of(c); A.V_type = c->vtype;
-    // Wave tile shape (speed only): memory is contiguous along the volume's x axis.  When the
-    // screen x direction maps (almost) onto it, a 32x2 tile lets the 32 lanes of a row read one
-    // or two cache lines (measured C3, view along z: 1.6 ms vs 2.1 ms for 8x8); otherwise the
-    // compact 8x8 tile touches the fewest lines.  VV_TILE_LOG2W overrides (3, 4 or 5).
-    A.strips.tile_log2w = 3;
-    if (have_basis) {
-        const float ax = fabsf(P.side[0]) , ay = fabsf(P.side[1]), az = fabsf(P.side[2]);
-        if (ax >= 0.97f * sqrtf(ax * ax + ay * ay + az * az)) A.strips.tile_log2w = 5;
-    }
-    const vv_knobs &K = c->knobs;
-    // z-fastest copy (speed only): when the screen x direction maps onto the volume's z axis (side views) the same 32 x 2 tile reads whole
-    // lines of a copy whose rows run along z -- the front view's kernel instead of the bricked copy's (C3 1.33 -> 1.0 ms, C2 0.223 -> 0.186,
-    // profiles/r04_side_view.txt).  Both voxel types, both kernels, every volume the bricked copy would serve; built on first use if HBM has
-    // room (one more copy of the volume).  VV_ZFAST=0/1 overrides.
-    bool use_zfast = false;
-    if (have_basis && A.strips.tile_log2w == 3) {
-        const float ax = fabsf(P.side[0]) , ay = fabsf(P.side[1]), az = fabsf(P.side[2]);
-        use_zfast = az >= 0.97f * sqrtf(ax * ax + ay * ay + az * az) && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
-        if (K.zfast >= 0) use_zfast = K.zfast != 0;
-    }
-    ++c->frame_no;
-    const unsigned long long builds_before = (unsigned long long)c->bricks_valid + c->zpair_valid + c->zfast_valid + c->xpair_valid;
-    if (use_zfast) use_zfast = c->build_in_render ? ensure_zfast(c, st) : c->zfast_valid;
-    if (use_zfast) {
-        c->last_used[CP_ZFAST] = c->frame_no;
-        A.strips.tile_log2w = 5;
-        A.V.zfast = c->d_zfast; A.V.zf_row_bytes = c->zf_row; A.V.zf_slice_bytes = c->zf_slice;
-    }
-    if (K.tile_log2w >= 3 && K.tile_log2w <= 5 && !use_zfast) A.strips.tile_log2w = K.tile_log2w;
-    // Occupancy cap + gathers in flight (speed only; measured on MI355X, profiles/EXPERIMENTS.md part B section 4):
-    //   volume beyond the caches (> 1 GiB), aligned view : 2 blocks per CU, 3 samples per trip
-    //   volume beyond the caches, rotated, linear layout : 1 block  per CU, 3 samples per trip
-    //   smaller volumes                                  : 4 blocks per CU, 3 (aligned) / 2 samples per trip
-    //   bricked copy (below)                             : 2 / 4 blocks per CU, 2 samples per trip
-    // LDS per block = 4 KB table + reserve; 160 KB per CU.  VV_LDS_RESERVE / VV_UNROLL override.
-    // XCD-aware block order: XCD k renders strips k, k+8, ... (each a full-width row of tiles), so
-    // the tiles that share volume cache lines share an L2 (measured: -4 % on every workload)
-    A.strips.xcd_band = 1;
-    if (K.xcd_band >= 0 && K.xcd_band <= 64) A.strips.xcd_band = K.xcd_band;
-    const bool beyond_caches = c->vol_bytes > (1ull << 30);
-    // Sampling density: voxels of volume per sample = (voxels per step) x (voxels per pixel)^2 at the
-    // cube centre.  Sparse rays (C3 at 1080p: 4.9) reuse little of a cache line and want few waves on a CU's
-    // L1; the denser frames of the multi-GPU configurations (2716x1528: 2.5, 3840x2160: 1.2, and 0.6 at
-    // step 1/1024) want more: the whole 3840x2160 / 1024-step frame takes 3.51 ms with 2 blocks per CU and
-    // 2.71 ms with 4 (tools/sweep.sh --frame-of 8; bricked copy 4.71 -> 3.34 ms, Phong 9.0 -> 7.9 ms).
-    if ((rays->mode == VV_RAYS_ANALYTIC || image_source_has_hint(rays)) && have_basis && H > 0) {
-        const float dist = vlen_h(cam->origin[0], cam->origin[1], cam->origin[2]);
-        const float vpw = cbrtf(((float)c->nx / (2.f * P.scale[0])) * ((float)c->ny / (2.f * P.scale[1])) * ((float)c->nz / (2.f * P.scale[2])));
-        const float px_vox = 2.f * P.tan_half_y * dist / (float)H * vpw;
-        const float step_vox = fmaxf(P.step[0] * c->nx, fmaxf(P.step[1] * c->ny, P.step[2] * c->nz));
-        if (std::isfinite(px_vox) && std::isfinite(step_vox) && px_vox > 0.f && step_vox > 0.f) density = step_vox * px_vox * px_vox;
-    }
-    const int big_reserve = density > 3.5f ? 76000 : (density > 1.8f ? 49000 : 36000);   // 2 / 3 / 4 blocks per CU
-    // 3 samples per trip along the memory axis (A/B with repeats on MI355X: C3 -1.6 %, C2 -5.7 %, 512^3 -10 %,
-    // u8 1024^3 -6.5 %; 4 per trip is no better), 2 on the bricked copy (3 there: +3.5 %)
-    A.unroll = (A.strips.tile_log2w == 5 || beyond_caches) ? 3 : 2;
-    // (re-swept with tools/ab_reserve.sh at the end of round 1: 4 blocks per CU for volumes up to 1 GiB)
-    A.lds_reserve = !beyond_caches ? 36000 : (A.strips.tile_log2w == 5 ? big_reserve : 155000);
-    // Block shape (speed only).  32 x 2 wave tiles: stacked (32 x 8 pixels), 2 x 2 (64 x 4) or side by side (128 x 2): the partial lines two x-adjacent wave
-    // tiles share are then fetched within one block; strips get lower.  8 x 8 wave tiles: side by side (32 x 8), 2 x 2 (16 x 16) or stacked (8 x 32).  VV_BLOCK_W=8...128.
-    //   measured (tools/ab_env.sh, profiles/r03_block_shape.txt): 64 x 4: C3 -2.4 % (EA bytes 1.474 -> 1.364 x algorithmic), u8 1024^3 -1.3 %, tilted views -1.7 %, but
-    //   +4.5 % on C2, +1 % on C1 / 512^3 and +0.5 % on the dense frames of the multi-GPU configurations: used for sparse frames of volumes beyond the caches.
-    //   16 x 16: a strip 16 pixels high re-reads fewer brick layers of its neighbours (which run on other XCDs): rotated C3 -2 % (EA bytes 2.00 -> 1.81 x), C2 -5.5 %,
-    //   C1 -6.5 %, other orbits -2 ... -4 %, 512^3 and the 3840 x 2160 frame -0.5 %: used for every frame with 8 x 8 tiles.
-    A.strips.blk_log2w = 5;
-    A.strips.tail_batch = K.tail == 0 ? 0 : 1;
-    const int rows_px_8 = A.strips.n_strips * 8;              // (the shard's pixel rows as strips of 8)
-    int block_w = A.strips.tile_log2w == 3 ? 16 : ((A.strips.tile_log2w == 5 && c->vol_bytes >= (1ull << 30) && density > 3.5f) ? 64 : 32);      // (>=: u8 1024^3 -2 %, tools/policy_sweep.sh)
-    if (K.block_w >= 8 && K.block_w <= 128 && (K.block_w & (K.block_w - 1)) == 0) block_w = K.block_w;
-    {
-        int lw = 3; while ((1 << lw) < block_w) ++lw;
-        const int h = 256 >> lw;                               // strip height in pixels
-        if (lw != 5 && lw >= A.strips.tile_log2w && h >= (64 >> A.strips.tile_log2w)) {     // (a block is at least one wave tile wide and high)
-            A.strips.blk_log2w = lw;
-            // rows past the end of a band or of the range belong to nobody or to another rank: not owned (row_owned), their lanes stay idle
-            if (A.strips.strips_per_band < (1 << 26)) {
-                const int band_px = A.strips.strips_per_band * 8, spb = (band_px + h - 1) / h;
-                A.strips.n_strips = (rows_px_8 / band_px) * spb; A.strips.strips_per_band = spb;
-            } else A.strips.n_strips = (rows_px_8 + h - 1) / h;
-        }
-    }
-    const bool k_unroll = K.unroll >= 1 && K.unroll <= 3, k_reserve = K.lds_reserve >= 0 && K.lds_reserve <= 155 * 1024;
-    if (k_unroll) A.unroll = K.unroll;
-    if (k_reserve) A.lds_reserve = K.lds_reserve;
-    // Bricked copy (speed only): off the memory axis the linear layout costs one cache line per lane
-    // and gather; 4x4x4 bricks keep a wave's footprint in a few dozen lines.  both voxel types, both kernels;
-    // built on first use if HBM has room (1.25x an f32 volume, 2x a u8 volume).  VV_BRICKED=0/1 overrides the policy.
-    // Measured: 1024^3 rotated 3.85 -> 1.65 ms (f32), 3.17 -> 0.99 ms (u8); C2 (256^3) -19 %, C1 (128^3) -9 %;
-    // only volumes far below the frame's sampling density lose (64^3 at 1080p, step 1/512: +10 %).
-    bool use_bricks = A.strips.tile_log2w == 3 && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
-    if (K.bricked >= 0) use_bricks = K.bricked != 0;
-    if (use_zfast) use_bricks = false;
-    if (use_bricks) use_bricks = c->build_in_render ? ensure_bricks(c, st) : c->bricks_valid;
-    if (use_bricks) {
-        c->last_used[CP_BRICKS] = c->frame_no;
-        A.V.bricks = c->d_bricks; A.V.b_sy = c->b_sy; A.V.b_sz64 = c->b_sz64;
-        // measured (C3 rotated, 1024^3): 2 blocks per CU and 2 samples per trip: 3.64 -> 1.60 ms
-        if (!k_unroll) A.unroll = 2;
-        if (!k_reserve) A.lds_reserve = beyond_caches ? big_reserve : 36000;
-    }
-    // z-pair copy (speed only): along the memory axis the four corners (x..x+1, z..z+1) of a row come
-    // from one gather (16 bytes for f32, 4 for u8), so a sample costs 2 gathers instead of 4 (f32) or 8
-    // aligned dwords (u8).  2x the volume in HBM.  Measured on MI355X, unshaded frames:
-    //   f32: -7 % on C1/C2, -10 % on 256^3 at C3's frame, -3 % on 512^3, but +6 % on 768^3 and +20 % on
-    //        1024^3 (rays of different z phase stop sharing slices in L2): used up to 512 MiB;
-    //   u8 : -8 % (256^3), -12 % (512^3), -4 % (1024^3): used whenever the copy stays below 4 GiB;
-    //   Phong path: 0...-3 %: not used.                                  VV_ZPAIR=0/1 overrides.
-    bool use_zpair = !use_bricks && A.strips.tile_log2w == 5 && !shading->phongShading &&
-                     (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20));
-    if (K.zpair >= 0) use_zpair = K.zpair != 0 && !use_bricks;
-    if (use_zfast) use_zpair = false;
-    if (use_zpair) use_zpair = c->build_in_render ? ensure_zpair(c, st) : c->zpair_valid;
-    if (use_zpair) { c->last_used[CP_ZPAIR] = c->frame_no; A.V.zpair = c->d_zpair; A.V.zp_row_bytes = c->zp_row; A.V.zp_slab_bytes = c->zp_slab; }
-    // x-pair copy (speed only): the same two-gather form for side views -- the z-pair copy with x and z exchanged, handed to the kernel in the
-    // z-pair fields of the view -- under the z-pair copy's conditions (unshaded, u8 or f32 up to 512 MiB).  Follows VV_ZPAIR=0.
-    A.xpair = false;
-    if (use_zfast && !shading->phongShading && K.zpair != 0 && (c->vtype == VV_VOXEL_U8 || c->vol_bytes <= (512ull << 20)) &&
-        (c->build_in_render ? ensure_xpair(c, st) : c->xpair_valid)) {
-        A.xpair = true; c->last_used[CP_XPAIR] = c->frame_no;
-        A.V.zpair = c->d_xpair; A.V.zp_row_bytes = c->xp_row; A.V.zp_slab_bytes = c->xp_slab;
-    }
-    c->builds_in_render += ((unsigned long long)c->bricks_valid + c->zpair_valid + c->zfast_valid + c->xpair_valid > builds_before)
-                           ? ((unsigned long long)c->bricks_valid + c->zpair_valid + c->zfast_valid + c->xpair_valid - builds_before) : 0;
-    // Phong kernel: 14.3 KB of LDS per block + this reserve.  Measured (tools/ab_phong.sh): volumes up to
-    // 1 GiB like 5 blocks per CU (C2 0.54 -> 0.47 ms against no cap, u8 1024^3 1.88 -> 1.78), the 4 GiB
-    // volume of C3 3 blocks (2.77 ms with 2, 2.48 with 3, 2.54 with 4), the 32 GiB volume of C5 2 (18.2 vs 20.2 ms)
-    // (re-swept with the depth-limited refresh, tools/ab_phong_reserve.sh: C3 1.97 ms with 3, 4 or 5 blocks, 2.22 with 2; the
-    // bricked copy likes 5: rotated C3 + Phong 2.25 -> 2.13 ms; C5 5.95 ms with 2, 6.25 with 3, 6.55 with 5)
-    A.lds_reserve_phong = c->vol_bytes > (8ull << 30) ? 40000 : ((beyond_caches && density > 3.5f && !use_bricks) ? 30000 : 13000);
-    if (K.lds_reserve_phong >= 0 && K.lds_reserve_phong <= 146 * 1024) A.lds_reserve_phong = K.lds_reserve_phong;
+    const bool beyond_caches = choose_launch(c, A, cam, rays, shading, have_basis, density, H, st);
+    density = c->last_density;
     A.gray = c->tf_gray; A.phong = shading->phongShading;
     A.tf = c->d_tf;
     int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));

@@ -626,6 +626,9 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
         }
         __syncthreads();
         if (mine) {
+#ifdef VV_PHONG_SHADE_UNROLL
+#pragma unroll VV_PHONG_SHADE_UNROLL
+#endif
             for (int i = 1; i < kCacheDepth - 1; ++i) {
 #pragma clang fp contract(off)
                 float vd = (float)i * r.sstep + dist;                                 // :254
