@@ -626,19 +626,21 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
         }
         __syncthreads();
         if (mine) {
-#ifdef VV_PHONG_SHADE_UNROLL
-#pragma unroll VV_PHONG_SHADE_UNROLL
-#endif
+            // the ray's own cache column as a rolling window (entries i - 1, i, i + 1): one byte read per sample instead of three, and the table look-up of
+            // sample i no longer waits for a byte read of the same iteration (C3 + Phong -0.6 %, C2 + Phong -1.4 %, others +-0.3 %)
+            uint32_t s_prev = cache[0][tid], s_cur = cache[1][tid];
             for (int i = 1; i < kCacheDepth - 1; ++i) {
 #pragma clang fp contract(off)
                 float vd = (float)i * r.sstep + dist;                                 // :254
                 if (vd > r.upper) break;
                 if (INSTR) executed++;
-                uint32_t s = cache[i][tid];
+                const uint32_t s = s_cur, s_next = cache[i + 1][tid];                 // (entry i + 1 <= n + 1: inside the refreshed depth)
+                const uint32_t s_before = s_prev;
+                s_prev = s_cur; s_cur = s_next;
                 float4 e = lds_tf[s];
                 float cr = e.x, cg = e.y, cb = e.z, ca = e.w;
                 if (ca > kEps) {                                                      // :164 (phong is on)
-                    const uint32_t qf = cache[i - 1][tid], qa = cache[i + 1][tid];
+                    const uint32_t qf = s_before, qa = s_next;
                     const uint32_t ql = cache[i][nl], qr = cache[i][nr], qt = cache[i][nt], qb = cache[i][nb];
                     float direct = 0.f;
                     // all three central differences zero (inside a plateau): the gradient is (0,0,0),
