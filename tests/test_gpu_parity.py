@@ -1410,3 +1410,54 @@ def test_frames_enqueued_back_to_back():
         want_i, _ = O.render(vol, tf, W, H, cams[1], rays=vv.image_rays(front, back), options=o, fill=0x5A)
         assert np.array_equal(got_i, want_i)
         assert np.array_equal(c.render(W, H, cams[0], options=o, fill=0x5A), want[0])
+
+
+def test_screen_rectangle_launch(ctx, monkeypatch):
+    """Analytic frames launch the march kernels only over the tiles / slabs under the volume's screen rectangle and let rad_kernel write the 0 of
+    every pixel beside it (vv_api.cpp: screen_rect).  The frame must not depend on that: cameras that put the cube partly or wholly off the screen,
+    far away, close to the eye's plane, under a narrow and a wide lens, scaled cubes, frames of 14 k + 1 pixels (pin 10), row ranges and shards,
+    with and without Phong, a prefilled caller buffer (column W-1 / row H-1 and foreign rows keep their bytes) -- against the oracle, and against
+    the same library with the rectangle switched off (VV_RECT=0)."""
+    rng = np.random.default_rng(5150)
+    vol = O.noise_u8(20, 24, 28, 3).astype(np.float32) / np.float32(255)
+    tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
+    ctx.load_volume(vol, tf)
+    cams = [vv.Camera(origin=(0.0, 0.0, -4.0), look_at=(2.4, 0.0, 0.0)),                  # cube at the left edge, partly off
+            vv.Camera(origin=(0.0, 0.0, -4.0), look_at=(0.0, 3.0, 0.0)),                  # ... at the bottom edge
+            vv.Camera(origin=(0.0, 0.0, -4.0), look_at=(9.0, 0.0, 0.0)),                  # wholly off the screen
+            vv.Camera(origin=(0.0, 0.0, -40.0), fov_y=4.0),                               # far away, long lens
+            vv.Camera(origin=(0.0, 0.0, -400.0), fov_y=0.4),
+            vv.Camera(origin=(0.3, 0.2, -1.6), fov_y=100.0),                              # close: corners near the eye's plane
+            vv.Camera(origin=(0.0, 0.0, -1.0005)),                                        # on the cube's face: no rectangle
+            vv.Camera(origin=(1.3, 0.9, -2.2), look_at=(0.2, -0.1, 0.0), scale=(0.4, 1.0, 0.25)),
+            vv.Camera(origin=(-3.0, 2.0, 2.5), scale=(1.5, 0.3, 0.8), up=(0.2, 1.0, 0.1)),
+            vv.Camera.orbit(4.0, 1.0, 0.6, fov_y=20.0),
+            vv.Camera.orbit(6.0, 0.4, -1.2, look_at=(0.5, 0.5, -0.5))]
+    sizes = [(170, 113), (113, 57), (29, 43), (64, 15), (200, 150)]
+    n_case = 0
+    for ci, cam in enumerate(cams):
+        for phong in (False, True):
+            W, H = sizes[(ci + phong) % len(sizes)]
+            for opts_kw in ({}, {"shard": (4, 2, (ci + phong) % 2)}, {"slab_rows": (1, 3)}):
+                if opts_kw.get("slab_rows") and H < 43: continue
+                kw = dict(count_samples=True)
+                if "shard" in opts_kw: kw["shard"] = opts_kw["shard"]
+                if "slab_rows" in opts_kw: kw["slab_rows"] = opts_kw["slab_rows"]
+                want, n_want = O.render(vol, tf, W, H, cam, phong=phong, fill=7, options=vv.make_options(**kw))
+                got = ctx.render(W, H, cam, phong=phong, fill=7, options=vv.make_options(**kw))
+                assert_frames_close(got, want, f"camera {ci} phong {phong} {W}x{H} {opts_kw}")
+                assert ctx.last_sample_count() == n_want, (ci, phong, opts_kw)
+                n_case += 1
+    # the same frames with the rectangle off: one library, two launch geometries
+    monkeypatch.setenv("VV_RECT", "0")
+    c2 = vv.Context(0)
+    try:
+        c2.load_volume(vol, tf)
+        for ci, cam in enumerate(cams):
+            for phong in (False, True):
+                W, H = sizes[(ci + 2 * phong) % len(sizes)]
+                a = ctx.render(W, H, cam, phong=phong, fill=9); b = c2.render(W, H, cam, phong=phong, fill=9)
+                assert np.array_equal(a, b), (ci, phong)
+    finally:
+        c2.close() if hasattr(c2, "close") else None
+    assert n_case >= 50

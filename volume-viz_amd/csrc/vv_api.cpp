@@ -8,6 +8,7 @@
 #include "vv_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +24,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, zfast = -1, force_big = 0;
-    int block_w = -1, tail = -1;
+    int block_w = -1, tail = -1, rect = -1;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
     {
@@ -32,6 +33,7 @@ struct vv_knobs {
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
         block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1);
         zfast = geti("VV_ZFAST", -1); force_big = getenv("VV_FORCE_BIG") != nullptr;
+        rect = geti("VV_RECT", -1);
     }
 };
 
@@ -910,6 +912,37 @@ static bool choose_launch(vv_context *c, MarchArgs &A, const camera_params *cam,
     return beyond_caches;
 }
 
+// The volume's screen rectangle (speed only in intent, but the frame relies on it: see below).  Analytic rays only.  Of C3's 8100 tiles 5150 lie beside the
+// cube: blocks that set up 256 rays, find none alive and leave -- 2 us each, plus the ~4 us a slot stands empty between two blocks (per-block time stamps,
+// tools/timeline.py): together 6 % of the frame's slot time.  march_kernel is therefore launched over the tiles under the cube's bounding rectangle only, and
+// rad_kernel, which visits every slab anyway, writes the 0 of the pixels outside it and skips the radii nobody reads.
+// The rectangle must contain every pixel whose ray meets the cube.  A ray that meets the cube passes through a point of it, so its pixel lies in the convex hull
+// of the eight projected corners -- in exact arithmetic.  ray_endpoints decides in binary32: its direction carries an error of a few ulps (|d| ~ 1) and its slab
+// test errors of a few ulps of (|o| + s) / |d_a|; a ray can be taken for a hit only if it passes the cube within ~1e-6 (|o| + s).  Seen from the eye that is an
+// angle of at most 1e-6 (|o| + s) / depth_min, which the margin below covers a hundred times over, expressed in pixels (+ 1); a corner at or behind the eye's plane
+// (depth <= 1e-3 (|o| + s)), a margin wider than the frame or anything non-finite: no rectangle, the whole frame is launched as before.
+static bool screen_rect(const MarchArgs &A, int W, int H, double *xmin, double *xmax, double *ymin, double *ymax)
+{
+    const FrameParams &P = A.P;
+    double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY}, dmin = INFINITY, ext = 0.0;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, (double)fabsf(P.cam_pos[a]) + (double)P.scale[a]);
+    for (int k = 0; k < 8; ++k) {
+        const double v[3] = {((k & 1) ? P.scale[0] : -P.scale[0]) - (double)P.cam_pos[0], ((k & 2) ? P.scale[1] : -P.scale[1]) - (double)P.cam_pos[1],
+                             ((k & 4) ? P.scale[2] : -P.scale[2]) - (double)P.cam_pos[2]};
+        const double depth = v[0] * P.look[0] + v[1] * P.look[1] + v[2] * P.look[2];
+        if (!(depth > 1e-3 * ext)) return false;
+        dmin = std::min(dmin, depth);
+        const double sx = (v[0] * P.side[0] + v[1] * P.side[1] + v[2] * P.side[2]) / depth, sy = (v[0] * P.up[0] + v[1] * P.up[1] + v[2] * P.up[2]) / depth;
+        const double px = (sx / P.tan_half_x + 1.0) * 0.5 * W - 0.5, py = (sy / P.tan_half_y + 1.0) * 0.5 * H - 0.5;     // (ray_endpoints' pixel centres)
+        lo[0] = std::min(lo[0], px); hi[0] = std::max(hi[0], px); lo[1] = std::min(lo[1], py); hi[1] = std::max(hi[1], py);
+    }
+    const double ang = 1e-4 * ext / dmin;                                                       // (100 x the bound above)
+    const double mx = 1.0 + ang / (2.0 * P.tan_half_x / W), my = 1.0 + ang / (2.0 * P.tan_half_y / H);
+    if (!std::isfinite(lo[0] + hi[0] + lo[1] + hi[1] + mx + my) || mx > W || my > H) return false;
+    *xmin = lo[0] - mx; *xmax = hi[0] + mx; *ymin = lo[1] - my; *ymax = hi[1] + my;
+    return true;
+}
+
 extern "C" {
 
 int vv_render(vv_context *c, int W, int H, const slice_params *slice, const camera_params *cam,
@@ -1066,6 +1099,46 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     const bool beyond_caches = choose_launch(c, A, cam, rays, shading, have_basis, density, H, st);
     density = c->last_density;
     A.gray = c->tf_gray; A.phong = shading->phongShading;
+    // march_kernel's tiles: those under the volume's screen rectangle (screen_rect), or all of them
+    {
+        StripMap &M = A.strips;
+        const int bw = 1 << M.blk_log2w, bh = 256 >> M.blk_log2w;
+        M.tx0 = 0; M.wr = (W + bw - 1) >> M.blk_log2w; M.s0 = 0; M.s1 = M.n_strips;
+        A.rect.x0 = 0; A.rect.y0 = 0; A.rect.x1 = INT_MAX; A.rect.y1 = INT_MAX;
+        double xmin, xmax, ymin, ymax;
+        SlabMap &S = A.slabs;
+        S.gx0 = 0; S.wg = P.nbx; S.gs0 = 0; S.gs1 = S.n_regular;
+        A.fill_outside = false;
+        const bool have_rect = c->knobs.rect != 0 && rays->mode == VV_RAYS_ANALYTIC && W >= 2 && H >= 2 && screen_rect(A, W, H, &xmin, &xmax, &ymin, &ymax);
+        if (have_rect && A.phong && S.n_regular > 0) {
+            // march_phong_kernel: the slabs whose own 14 x 14 pixels meet the rectangle.  A pixel is written by the slab that owns it (pin 10): when W == 1 (mod 14)
+            // pixel column W-2 lies in slab column nbx-2 and belongs to nbx-1, which therefore comes along; the extra slab row is always launched.
+            auto slab_of = [](double v, int lo, int hi) { const double t = floor(v / kSlab); return t < lo ? lo : (t > hi ? hi : (int)t); };
+            int gx0 = slab_of(xmin, 0, P.nbx), gx1 = slab_of(xmax, -1, P.nbx - 1) + 1;
+            if (P.conflict_x && gx1 == P.nbx - 1) gx1 = P.nbx;
+            if (gx1 < gx0) gx1 = gx0;
+            S.gx0 = gx0; S.wg = gx1 - gx0;
+            A.rect.x0 = gx0 * kSlab; A.rect.x1 = gx1 >= P.nbx ? INT_MAX : gx1 * kSlab;
+            if (s_count <= 1) {
+                S.gs0 = slab_of(ymin, S.r0, S.r0 + S.n_regular) - S.r0; S.gs1 = slab_of(ymax, S.r0 - 1, S.r0 + S.n_regular - 1) + 1 - S.r0;
+                if (S.gs1 < S.gs0) S.gs1 = S.gs0;
+                A.rect.y0 = (S.r0 + S.gs0) * kSlab; A.rect.y1 = (S.r0 + S.gs1) * kSlab;
+            }
+            if (S.wg == 0 || S.gs1 == S.gs0) { S.wg = 0; A.rect.x0 = A.rect.x1 = A.rect.y0 = A.rect.y1 = 0; }
+            A.fill_outside = true;
+        }
+        if (have_rect && !A.phong && M.n_strips > 0) {
+            auto tile_of = [](double v, int unit, int lo, int hi) { const double t = floor(v / unit); return t < lo ? lo : (t > hi ? hi : (int)t); };
+            const int ntx = M.wr;
+            M.tx0 = tile_of(xmin, bw, 0, ntx); M.wr = tile_of(xmax, bw, -1, ntx - 1) + 1 - M.tx0;
+            if (s_count <= 1) { M.s0 = tile_of(ymin - M.y0, bh, 0, M.n_strips); M.s1 = tile_of(ymax - M.y0, bh, -1, M.n_strips - 1) + 1; }
+            if (M.wr < 0) M.wr = 0;
+            if (M.s1 < M.s0) M.s1 = M.s0;
+            A.rect.x0 = M.tx0 * bw; A.rect.x1 = (M.tx0 + M.wr) * bw;
+            if (s_count <= 1) { A.rect.y0 = M.y0 + M.s0 * bh; A.rect.y1 = M.y0 + M.s1 * bh; }
+            if (M.wr == 0 || M.s1 == M.s0) { A.rect.x0 = A.rect.x1 = A.rect.y0 = A.rect.y1 = 0; }       // (the cube is off the screen: every pixel is rad_kernel's)
+        }
+    }
     A.tf = c->d_tf;
     int rc = ensure(c, (void **)&c->d_rad, &c->rad_cap, (size_t)P.nbx * P.nby * sizeof(float));
     if (rc) return rc;
@@ -1088,6 +1161,9 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (((uintptr_t)d_out & 3) != 0) return fail(c, VV_ERR_INVALID, "vv_render: output buffer must be 4-byte aligned");
 
     if (A.instr) HIPCHK(c, hipMemsetAsync(c->d_counter, 0, 16 * sizeof(unsigned long long), st));
+#ifdef VV_TIMELINE
+    { const char *e = getenv("VV_TIMELINE_PTR"); A.I.timeline = e ? (unsigned long long *)strtoull(e, nullptr, 0) : nullptr; }
+#endif
     c->counter_valid = A.instr;
     {
         const int layout = A.xpair ? 5 : A.V.zfast ? 4 : (A.V.bricks ? 2 : (A.V.zpair ? 3 : ((A.V.big || (A.phong && beyond_caches)) ? 1 : 0)));
@@ -1097,6 +1173,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     }
     HIPCHK(c, hipEventRecord(c->ev0, st));
     if (A.phong) {
+        if (A.fill_outside) { A.rad_out = nullptr; launch_rad(A, st); }          // the pixels beside the volume's screen rectangle (rad_kernel writes them; no radii here)
         // (linear volumes beyond the caches take the 64-bit-addressing build even below 4 GiB: the other one is compiled for 5 waves per SIMD, which only
         //  cache-resident volumes want -- 1000^3 f32: 1.884 -> 1.817 ms, tools/ab_env.sh VV_FORCE_BIG=1)
         if (A.xpair) launch_raymarch_xpair(A, st); else if (A.V.zfast) launch_raymarch_zfast(A, st); else if (A.V.bricks) { if (beyond_caches) launch_raymarch_bricked(A, st); else launch_raymarch_bricked_cached(A, st); } else if (A.V.zpair) launch_raymarch_zpair(A, st); else if (A.V.big || beyond_caches) launch_raymarch_big(A, st); else launch_raymarch(A, st);

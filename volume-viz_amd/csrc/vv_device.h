@@ -607,6 +607,9 @@ struct InstrArgs {
                              // 1: lines of every gather the kernel issues, idle lanes and out-of-volume samples included
     unsigned long long *pairs;   // open-addressing hash set of (block, line) pairs, 2^pairs_log2 zero-initialised words, or NULL: the lines each
     uint32_t  pairs_log2;        // block touches, counted per block (what the frame fetches if nothing is shared between blocks)
+#ifdef VV_TIMELINE
+    unsigned long long *timeline;   // experiment builds only (tools/timeline.py): 4 words per block of march_kernel -- start, end (100 MHz clock), strip << 16 | tile, XCC | live << 8
+#endif
 };
 __device__ __forceinline__ void mark_line_range(const InstrArgs &I, uint64_t off, uint32_t bytes)
 {

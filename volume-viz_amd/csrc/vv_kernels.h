@@ -8,9 +8,18 @@ namespace vv {
 // blockIdx.y -> pixel strip (march_kernel) / slab row (march_phong_kernel) of a shard
 struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips, xcd_band;
                   int tail_batch;     // march_kernel: chunks that hold at most one sample per lane (rays past the ERT threshold) are taken U at a time
-                  int blk_log2w; };   // a block covers 2^blk_log2w x (256 >> blk_log2w) pixels (5: 32 x 8; 32 x 2 tiles also 64 x 4 / 128 x 2, 8 x 8 tiles 16 x 16 / 8 x 32); strips are that high
+                  int blk_log2w;      // a block covers 2^blk_log2w x (256 >> blk_log2w) pixels (5: 32 x 8; 32 x 2 tiles also 64 x 4 / 128 x 2, 8 x 8 tiles 16 x 16 / 8 x 32); strips are that high
+                  // march_kernel launches the tiles of columns [tx0, tx0 + wr) of strips [s0, s1) only: the tiles under the volume's screen rectangle
+                  // (vv_render: screen_rect) -- or all of them: tx0 = 0, wr = tile columns of the frame, s0 = 0, s1 = n_strips
+                  int tx0, wr, s0, s1; };
+// the same rectangle in pixels: [x0, x1) x [y0, y1).  Every owned pixel outside it is a pixel whose ray misses the volume: rad_kernel writes its 0,
+// and computes no radius for slabs that do not meet the rectangle (march_kernel, which reads them, is not launched there).  No rectangle: x1 = y1 = INT_MAX.
+struct PixelRect { int x0, x1, y0, y1; };
 
-struct SlabMap  { int r0, band, band_stride, n_regular; };
+struct SlabMap  { int r0, band, band_stride, n_regular;
+                  // march_phong_kernel launches slab columns [gx0, gx0 + wg) of the grid rows [gs0, gs1) and the extra row n_regular (pin 10): the slabs under the
+                  // volume's screen rectangle, or all of them (gx0 = 0, wg = nbx, gs0 = 0, gs1 = n_regular)
+                  int gx0, wg, gs0, gs1; };
 
 struct MarchArgs {
     FrameParams P;
@@ -22,6 +31,8 @@ struct MarchArgs {
     int unroll;                 // march_kernel: samples per loop trip (2 or 3)
     int lds_reserve_phong;      // march_phong_kernel: same occupancy cap (its own LDS is 14 KB)
     StripMap strips;                   // march_kernel: strips of 8 pixel rows (n_strips of them)
+    PixelRect rect;                    // rad_kernel + march kernels: the pixels the march kernel's tiles / slabs cover
+    bool fill_outside;                 // Phong frames: rad_kernel is launched (without radii) to write the pixels outside `rect`
     SlabMap slabs;                     // march_phong_kernel grid.y = n_regular + 1
     const float4 *tf;           // device, 256 entries
     const float *rad;           // device, nbx*nby (read by march_kernel)

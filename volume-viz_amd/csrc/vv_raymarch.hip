@@ -113,7 +113,7 @@ __device__ __noinline__ void mark_sample_lines(const InstrArgs &I, const VolumeV
 // pixels per lane, minimum by wave shuffles -- no LDS, no block barrier.  The minimum of a set of
 // floats does not depend on the order fminf visits them in, so the value equals the reference's tree.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rad_kernel(FrameParams P, float *__restrict__ rad)
+__global__ __launch_bounds__(256) void rad_kernel(FrameParams P, float *__restrict__ rad, PixelRect R, uint32_t *__restrict__ pixels)
 {
     const int slab = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (slab >= P.nbx * P.nby) return;                                     // wave-uniform
@@ -121,6 +121,22 @@ __global__ __launch_bounds__(256) void rad_kernel(FrameParams P, float *__restri
     // a shard only needs the radii of the slab rows that own its pixel rows: its own bands
     // (bands are whole slab rows) and, when H == 1 (mod 14), the last slab row (pin 10)
     if (!row_owned(P, by * kSlab) && !(P.conflict_y && by == P.nby - 1)) return;
+    // Pixels outside the rectangle march_kernel's tiles cover: their rays miss the volume (vv_render: screen_rect), the frame holds 0 there
+    // (kernel.cu:334-338).  This wave writes the ones among the slab's 14 x 14 pixels that the frame owns (not column W-1 / row H-1, not another shard's rows).
+    const int sx0 = bx * kSlab, sy0 = by * kSlab;
+    const bool meets = sx0 < R.x1 && sx0 + kSlab > R.x0 && sy0 < R.y1 && sy0 + kSlab > R.y0;
+    const bool inside = sx0 >= R.x0 && sx0 + kSlab <= R.x1 && sy0 >= R.y0 && sy0 + kSlab <= R.y1;
+    if (!inside && row_owned(P, sy0)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = lane + 64 * q, tx = t % kSlab, ty = t / kSlab;
+            const int x = sx0 + tx, y = sy0 + ty;
+            if (t < kSlab * kSlab && x <= P.W - 2 && y <= P.H - 2 && !(x >= R.x0 && x < R.x1 && y >= R.y0 && y < R.y1)) pixels[(size_t)y * P.W + x] = 0u;
+        }
+    }
+    // no radius for a slab none of whose own pixels march_kernel visits (it reads rad[owner_slab(pixel)]); the slabs that own pixel W-2 / H-2
+    // without containing it (pin 10) always compute theirs
+    if (!rad || (!meets && !(P.conflict_x && bx == P.nbx - 1) && !(P.conflict_y && by == P.nby - 1))) return;      // (Phong frames: no radii wanted, march_phong_kernel finds its own)
     const int lox = slab_lo(bx), upx = slab_up(bx, P.W) - 1, loy = slab_lo(by), upy = slab_up(by, P.H) - 1;
     float m = 0.f;
 #pragma unroll
@@ -171,8 +187,11 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
 {
     __shared__ float lds_tf[1024];
 
+#ifdef VV_TIMELINE
+    const unsigned long long tl0 = wall_clock64();
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bl = M.blk_log2w, ntx = (P.W + (1 << bl) - 1) >> bl;        // block = 2^bl x (256 >> bl) pixels
+    const int bl = M.blk_log2w, ntx = M.wr;                               // block = 2^bl x (256 >> bl) pixels; the launch covers ntx tile columns from M.tx0 on
     int strip, tile_x;
     if (M.xcd_band > 0) {
         // XCD-aware order (speed only): linear block L runs on XCD L % 8 (round-robin dispatch);
@@ -180,14 +199,14 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         const int L = blockIdx.x, per_band = ntx * M.xcd_band;
         const int xcd = L & 7, j = L >> 3;
         const int band = (j / per_band) * 8 + xcd, w = j % per_band;
-        strip = band * M.xcd_band + w / ntx; tile_x = w % ntx;
-    } else { strip = blockIdx.x / ntx; tile_x = blockIdx.x % ntx; }
+        strip = M.s0 + band * M.xcd_band + w / ntx; tile_x = M.tx0 + w % ntx;
+    } else { strip = M.s0 + blockIdx.x / ntx; tile_x = M.tx0 + blockIdx.x % ntx; }
     // wave tile = 2^tw x 2^(6-tw) pixels; the 4 waves of a block tile a 32x8 strip
     const int tw = M.tile_log2w, th = 6 - tw;
     const int wx = wave & (((1 << bl) >> tw) - 1), wy = wave >> (bl - tw);
     const int x = (tile_x << bl) + (wx << tw) + (lane & ((1 << tw) - 1));
     const int y = M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * (256 >> bl) + (wy << th) + (lane >> tw);
-    if (strip >= M.n_strips) return;                       // block-uniform, before any barrier
+    if (strip >= M.s1) return;                             // block-uniform, before any barrier
     // The table entry this thread stages is loaded now and parked in LDS behind the ray set-up (which needs no table): its latency hides behind
     // the set-up's divisions instead of standing in front of them (blockDim.x == 256 == entries: every launch of this kernel).  C3 -0.6 %, C2 -1.1 %.
     const float4 tf_entry = tf[threadIdx.x];
@@ -391,6 +410,16 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         if (GRAY) { res_g = res_r; res_b = res_r; }
         pixels[(size_t)y * P.W + x] = write_zero ? 0u : pack_rgba(res_r, res_g, res_b, res_a);
     }
+#ifdef VV_TIMELINE
+    {
+        const bool any_live = __any(alive) != 0;
+        if (I.timeline && threadIdx.x == 0) {
+            unsigned long long *t = I.timeline + 4ull * blockIdx.x;
+            t[0] = tl0; t[1] = wall_clock64(); t[2] = ((unsigned long long)strip << 16) | (unsigned)tile_x;
+            t[3] = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) | (any_live ? 256u : 0u);      // HW_REG_XCC_ID
+        }
+    }
+#endif
     if (INSTR) {
         for (int o = 32; o > 0; o >>= 1) executed += __shfl_down(executed, o);
         if (lane == 0 && executed) atomicAdd(counter, executed);
@@ -459,14 +488,15 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
     const int tid = threadIdx.x;
     // XCD-aware order (speed only, as in march_kernel): linear block L runs on XCD L % 8; XCD k takes the
     // grid rows k, k+8, ... so that the slabs of one row, which share volume lines, share an L2
-    const int nbxg = P.nbx;
+    const int nbxg = M.wg;                   // (slab columns the launch covers, from M.gx0 on)
 #ifndef VV_PHONG_BAND
 #define VV_PHONG_BAND 1
 #endif
     constexpr int BAND = VV_PHONG_BAND;      // vertically adjacent slab rows per XCD, dispatched next to each other
     const int j_ = (int)blockIdx.x >> 3;
-    const int gx = (j_ / BAND) % nbxg, gy = ((j_ / (BAND * nbxg)) * 8 + ((int)blockIdx.x & 7)) * BAND + j_ % BAND;
-    if (gy > M.n_regular) return;                              // block-uniform, before any barrier
+    const int gx = M.gx0 + (j_ / BAND) % nbxg, lr = ((j_ / (BAND * nbxg)) * 8 + ((int)blockIdx.x & 7)) * BAND + j_ % BAND;
+    if (lr > M.gs1 - M.gs0) return;                            // block-uniform, before any barrier
+    const int gy = lr < M.gs1 - M.gs0 ? M.gs0 + lr : M.n_regular;     // (the launch's last row is the extra one)
     stage_tf(lds_tf, tf);
     // kernel.cu:175-177 divides six cached bytes by 255.f per shaded sample; a correctly rounded
     // division is ~10 instructions, a table look-up of the same quotient is one LDS read
@@ -704,10 +734,11 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
 template <int SLICE, int VOXEL, bool TEX8, bool GRAY, bool INSTR>
 static void launch_march(const MarchArgs &a, hipStream_t s)
 {
-    const int ntx = (a.P.W + (1 << a.strips.blk_log2w) - 1) >> a.strips.blk_log2w;
-    unsigned nblocks = (unsigned)(a.strips.n_strips * ntx);
+    const int ntx = a.strips.wr, ns = a.strips.s1 - a.strips.s0;          // the tiles under the volume's screen rectangle (StripMap)
+    if (ntx <= 0 || ns <= 0) return;
+    unsigned nblocks = (unsigned)(ns * ntx);
     if (a.strips.xcd_band > 0) {
-        const int nbands = (a.strips.n_strips + a.strips.xcd_band - 1) / a.strips.xcd_band;
+        const int nbands = (ns + a.strips.xcd_band - 1) / a.strips.xcd_band;
         nblocks = (unsigned)(((nbands + 7) / 8) * 8 * a.strips.xcd_band * ntx);
     }
     dim3 grid(nblocks);
@@ -723,9 +754,10 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
 template <int SLICE, int VOXEL, bool TEX8, bool INSTR>
 static void launch_phong(const MarchArgs &a, hipStream_t s)
 {
-    const int rows = a.slabs.n_regular + 1;                   // grid rows, dealt to the 8 XCDs round-robin
+    const int rows = a.slabs.gs1 - a.slabs.gs0 + 1;           // grid rows, dealt to the 8 XCDs round-robin
     constexpr int BAND = VV_PHONG_BAND;
-    dim3 grid((unsigned)(((rows + 8 * BAND - 1) / (8 * BAND)) * 8 * BAND * a.P.nbx));
+    if (a.slabs.wg <= 0) return;
+    dim3 grid((unsigned)(((rows + 8 * BAND - 1) / (8 * BAND)) * 8 * BAND * a.slabs.wg));
     hipLaunchKernelGGL((march_phong_kernel<SLICE, VOXEL, TEX8, INSTR>), grid, dim3(256), (size_t)a.lds_reserve_phong, s,
                        a.P, a.V, a.tf, a.slabs, a.pixels, a.counter, a.I);
 }
@@ -752,7 +784,7 @@ static void launch_rad_impl(const MarchArgs &a, hipStream_t s)
 {
     // one wave per slab of the frame; waves of slab rows this shard does not own exit at once
     dim3 grid((unsigned)((a.P.nbx * a.P.nby + 3) / 4));
-    hipLaunchKernelGGL(rad_kernel, grid, dim3(256), 0, s, a.P, a.rad_out);
+    hipLaunchKernelGGL(rad_kernel, grid, dim3(256), 0, s, a.P, a.rad_out, a.rect, a.pixels);
 }
 
 static void launch_raymarch_impl(const MarchArgs &a, hipStream_t s)
