@@ -338,17 +338,21 @@ def main():
     # see from a cold device) and reported as `ms_per_step_first` / `roofline.frac_first`, so both readings are on record.
     spinup = int(os.environ.get("VV_BENCH_SPINUP", "300"))
     cold_ms = None
+    # One GPU: the K frames are timed by ONE pair of HIP events around the region (on the stream the kernels are launched on), and vv_render's own
+    # per-frame event pair is switched off (vv_set_frame_timing): every event record is a packet the stream retires between two frames, 2-4 us each.
+    # N > 1 keeps a pair per frame (the ranks' kernel times are reported one by one).
     if world == 1:
+        ctx.set_frame_timing(False)
         for _ in range(args.warmup):
             ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong, rays=main_rays)
-        ce = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
+        ce0.record()
         for k in range(args.steps):
-            ce[k][0].record()
             ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong, rays=main_rays)
-            ce[k][1].record()
+        ce1.record()
         torch.cuda.synchronize()
-        cold_ms = float(np.mean([a.elapsed_time(b) for a, b in ce]))
+        cold_ms = ce0.elapsed_time(ce1) / args.steps
     for _ in range(spinup):
         ctx.render_device(W, H, cam, G.frames[0].data_ptr(), options=opts, stream=stream, phong=args.phong, rays=main_rays)
     torch.cuda.synchronize()
@@ -364,13 +368,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        b = k & 1
-        G.finish(b)
-        ev[k][0].record()
-        ctx.render_device(W, H, cam, G.frames[b].data_ptr(), options=opts, stream=stream, phong=args.phong, rays=main_rays)
-        ev[k][1].record()
-        submit(b)
+    if world == 1:
+        ev[0][0].record()
+        for k in range(args.steps):
+            ctx.render_device(W, H, cam, G.frames[k & 1].data_ptr(), options=opts, stream=stream, phong=args.phong, rays=main_rays)
+        ev[0][1].record()
+    else:
+        for k in range(args.steps):
+            b = k & 1
+            G.finish(b)
+            ev[k][0].record()
+            ctx.render_device(W, H, cam, G.frames[b].data_ptr(), options=opts, stream=stream, phong=args.phong, rays=main_rays)
+            ev[k][1].record()
+            submit(b)
     G.drain()                                        # every frame is complete on rank 0 inside the timed region
     torch.cuda.synchronize()
     if world > 1:
@@ -392,7 +402,8 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el[0])
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))    # rad + march kernels of this rank
+    # rad + march kernels of this rank, per frame (one GPU: the region's HIP-event time / K, frame to frame)
+    kern_ms = ev[0][0].elapsed_time(ev[0][1]) / args.steps if world == 1 else float(np.mean([a.elapsed_time(b) for a, b in ev]))
     kern_all = torch.tensor([kern_ms], dtype=torch.float64, device=rdev)
     if world > 1:
         gl = [torch.zeros_like(kern_all) for _ in range(world)]
@@ -600,7 +611,7 @@ def main():
         # -- C2 (BASELINE.json configs[1]): 256^3 f32, 1280x720, step 1/256, grey table (Head).  Lives in the caches: not HBM-bound;
         #    reported as Msamples/s with the VALU-issue fraction of a committed PMC pass
         try:
-            c2 = vv.Context(local)
+            c2 = vv.Context(local); c2.set_frame_timing(False)
             n2, W2, H2 = 256, 1280, 720
             a8 = torch.empty(n2 ** 3, dtype=torch.uint8, device=dev); c2.generate_noise_device(a8.data_ptr(), n2, n2, n2, 0x9E3779B9, stream)
             a32 = torch.empty(n2 ** 3, dtype=torch.float32, device=dev); c2.promote_device(a8.data_ptr(), a32.data_ptr(), n2 ** 3, stream)
@@ -636,7 +647,7 @@ def main():
             out["c2"] = {"error": f"{type(e).__name__}: {e}"}
         # -- the reference's own voxel type (kernel.cu:46,459: u8; f32 volumes are this build's extension): C3's frame on the 1024^3 volume as u8
         try:
-            cu = vv.Context(local)
+            cu = vv.Context(local); cu.set_frame_timing(False)
             nu = 1024
             u8v = torch.empty(nu ** 3, dtype=torch.uint8, device=dev); cu.generate_noise_device(u8v.data_ptr(), nu, nu, nu, 0x9E3779B9, stream)
             cu.load_volume_device(u8v.data_ptr(), vv.VOXEL_U8, nu, nu, nu, tf, stream); torch.cuda.synchronize()
@@ -659,7 +670,7 @@ def main():
             out["u8_volume"] = {"error": f"{type(e).__name__}: {e}"}
         # -- generator (drawDefaultBrain, volumegenerator.cpp:100-119): HIP against the CPU restatement on one thread (as the reference is), 128^3 and 1024^3
         try:
-            cg = vv.Context(local)
+            cg = vv.Context(local); cg.set_frame_timing(False)
             gen = {}
             for ng in (128, 1024):
                 g8 = torch.empty(ng ** 3, dtype=torch.uint8, device=dev)
@@ -687,7 +698,7 @@ def main():
         try:
             ctx.load_volume(np.zeros((4, 4, 4), np.uint8), tf)          # release the 4 GiB C3 volume first
             torch.cuda.empty_cache()
-            c5 = vv.Context(local)
+            c5 = vv.Context(local); c5.set_frame_timing(False)
             n5, W5, H5, per = 2048, 1920, 1080, 32
             b8 = torch.empty(n5 ** 3, dtype=torch.uint8, device=dev); c5.generate_noise_device(b8.data_ptr(), n5, n5, n5, 0x9E3779B9, stream); torch.cuda.synchronize()
             pin = torch.empty((per, n5, n5), dtype=torch.uint8).pin_memory()

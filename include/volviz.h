@@ -350,7 +350,11 @@ int  vv_layout_state(const vv_context *ctx, unsigned long long out[8]);
 int  vv_device_bytes(const vv_context *ctx, unsigned long long out[4]);
 
 /* ---- metrics (the reference only has a clock() overlay) ---------------- */
-float              vv_last_frame_ms(const vv_context *ctx);      /* hipEvent time of the last vv_render */
+float              vv_last_frame_ms(const vv_context *ctx);      /* hipEvent time of the last vv_render (-1: not timed) */
+/* Every vv_render brackets its kernels with two hipEventRecord (what vv_last_frame_ms reads): two more packets the stream has to retire per
+ * frame, ~2-4 us each back to back.  A host that times whole runs itself (bench.py) or does not time at all switches them off (on = 0);
+ * vv_last_frame_ms then returns -1.  Default: on, the reference's lastRenderTime overlay (glwidget.cpp:288-293) wants it. */
+int                vv_set_frame_timing(vv_context *ctx, int on);
 unsigned long long vv_last_sample_count(vv_context *ctx);        /* executed samples, if count_samples */
 int                vv_debug_last_launch(vv_context *ctx, int out[8]);  /* what the launch policy chose for the last vv_render (developer aid): wave tile log2 width,
                                                                        * block log2 width, samples per trip, LDS reserve, layout (0 linear, 1 linear/64-bit, 2 bricked,

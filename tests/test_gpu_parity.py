@@ -1461,3 +1461,18 @@ def test_screen_rectangle_launch(ctx, monkeypatch):
     finally:
         c2.close() if hasattr(c2, "close") else None
     assert n_case >= 50
+
+
+def test_frame_timing_switch(ctx):
+    """vv_set_frame_timing: the per-frame event pair behind vv_last_frame_ms can be switched off (hosts that time whole runs) and on again."""
+    ctx.load_volume(O.draw_default_brain(16, 16, 16), vv.transfer_preset(vv.TF_ENGINE))
+    a = ctx.render(56, 56, vv.Camera())
+    assert ctx.last_frame_ms() > 0
+    ctx.set_frame_timing(False)
+    try:
+        b = ctx.render(56, 56, vv.Camera())
+        assert ctx.last_frame_ms() == -1.0 and np.array_equal(a, b)
+    finally:
+        ctx.set_frame_timing(True)
+    ctx.render(56, 56, vv.Camera())
+    assert ctx.last_frame_ms() > 0

@@ -42,7 +42,7 @@ struct vv_context {
     vv_knobs knobs;
     hipStream_t stream = nullptr;          // used when the caller passes no stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    bool timed = false, time_frames = true;      // vv_set_frame_timing
     // volume
     void *d_vol = nullptr; size_t vol_bytes = 0; int vtype = VV_VOXEL_U8; int nx = 0, ny = 0, nz = 0;
     size_t row_pitch = 0, slice_pitch = 0, alloc_bytes = 0;   // linear layout in HBM (bytes); vol_bytes stays nx*ny*nz*voxel
@@ -1171,7 +1171,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
                           (int)fminf(density * 1000.f, 2e9f), A.phong ? 1 : 0};
         memcpy(c->last_launch, v, sizeof v);
     }
-    HIPCHK(c, hipEventRecord(c->ev0, st));
+    if (c->time_frames) HIPCHK(c, hipEventRecord(c->ev0, st));
     if (A.phong) {
         if (A.fill_outside) { A.rad_out = nullptr; launch_rad(A, st); }          // the pixels beside the volume's screen rectangle (rad_kernel writes them; no radii here)
         // (linear volumes beyond the caches take the 64-bit-addressing build even below 4 GiB: the other one is compiled for 5 waves per SIMD, which only
@@ -1186,9 +1186,9 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
         else if (A.V.big) launch_raymarch_big(A, st);
         else launch_raymarch(A, st);
     }
-    HIPCHK(c, hipEventRecord(c->ev1, st));
+    if (c->time_frames) HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, hipGetLastError());
-    c->timed = true;
+    c->timed = c->time_frames;
     if (!out_on_device) {
         if (whole) HIPCHK(c, hipMemcpy2DAsync(rgba_out, (size_t)W * 4, d_out, (size_t)W * 4, (size_t)(W - 1) * 4, (size_t)(H - 1), hipMemcpyDeviceToHost, st));
         else HIPCHK(c, hipMemcpyAsync(rgba_out, d_out, fb, hipMemcpyDeviceToHost, st));
@@ -1240,6 +1240,14 @@ int vv_debug_last_launch(vv_context *c, int out[8])
 {
     if (!c || !out) return VV_ERR_INVALID;
     memcpy(out, c->last_launch, sizeof c->last_launch);
+    return VV_OK;
+}
+
+int vv_set_frame_timing(vv_context *c, int on)
+{
+    if (!c) return fail(nullptr, VV_ERR_INVALID, "vv_set_frame_timing: NULL context");
+    c->time_frames = on != 0;
+    if (!on) c->timed = false;
     return VV_OK;
 }
 

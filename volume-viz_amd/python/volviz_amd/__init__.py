@@ -82,7 +82,7 @@ EXPORTS = [
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
     "vv_prepare_layouts", "vv_set_layout_policy", "vv_layout_state", "vv_device_bytes", "vv_reread_env",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
-    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset", "vv_debug_last_launch",
+    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset", "vv_debug_last_launch", "vv_set_frame_timing",
 ]
 
 _lib = None
@@ -144,6 +144,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_cut_plane_drag.argtypes = [vp, vp, vp, i, i, i, i]
     lib.vv_debug_counters.argtypes = [vp, vp]
     lib.vv_debug_last_launch.argtypes = [vp, vp]
+    lib.vv_set_frame_timing.argtypes = [vp, i]
     lib.vv_reread_env.argtypes = [vp]
     lib.vv_prepare_layouts.argtypes = [vp, i, vp]
     lib.vv_device_bytes.argtypes = [vp, vp]
@@ -395,6 +396,10 @@ class Context:
 
     def last_frame_ms(self) -> float:
         return float(self.lib.vv_last_frame_ms(self.h))
+
+    def set_frame_timing(self, on: bool) -> None:
+        """vv_set_frame_timing: the two hipEventRecord per vv_render behind last_frame_ms(), on (default) or off."""
+        self._chk(self.lib.vv_set_frame_timing(self.h, int(bool(on))))
 
     def debug_counters(self):
         out = np.zeros(16, np.uint64)
