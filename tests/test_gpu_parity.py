@@ -1476,3 +1476,32 @@ def test_frame_timing_switch(ctx):
         ctx.set_frame_timing(True)
     ctx.render(56, 56, vv.Camera())
     assert ctx.last_frame_ms() > 0
+
+
+def test_tile_order_table(ctx, monkeypatch):
+    """StripMap::order: analytic frames may march their tiles in the order of a table that rad_kernel's extra block builds (units of x-adjacent tiles, heaviest
+    first, dealt to the XCDs to and fro).  The policy uses it for aligned views of volumes up to 1 GiB; VV_LPT=1 forces it for every tile shape, VV_LPT_RUN
+    sets the unit length.  Frames and sample counts must not depend on it: aligned, oblique and side views, units longer and shorter than a strip, a frame
+    whose table ends in a partial round, shards and row ranges, against the oracle."""
+    rng = np.random.default_rng(77)
+    vol = O.noise_u8(36, 30, 33, 5).astype(np.float32) / np.float32(255)
+    tf = rng.uniform(0, 1, (256, 4)).astype(np.float32)
+    cams = [vv.Camera(), vv.Camera.orbit(4.0, np.pi / 3, np.pi / 5), vv.Camera.orbit(4.0, np.pi / 2, -np.pi / 2), vv.Camera.orbit(3.0, 0.5, 0.9, fov_y=60.0)]
+    want = {}
+    for ci, cam in enumerate(cams):
+        for kw in ({}, {"shard": (4, 2, 1)}, {"slab_rows": (2, 9)}):
+            key = (ci, tuple(sorted(kw.items())))
+            want[key] = O.render(vol, tf, 333, 211, cam, fill=3, options=vv.make_options(count_samples=True, **kw))
+    for env in ({"VV_LPT": "1"}, {"VV_LPT": "1", "VV_LPT_RUN": "1"}, {"VV_LPT": "1", "VV_LPT_RUN": "5"}, {"VV_LPT": "1", "VV_LPT_RUN": "64"},
+                {"VV_LPT": "3"}, {"VV_LPT": "1", "VV_BRICKED": "0"}, {"VV_LPT": "1", "VV_BLOCK_W": "128", "VV_TILE_LOG2W": "5"}):
+        for k in ("VV_LPT", "VV_LPT_RUN", "VV_BRICKED", "VV_BLOCK_W", "VV_TILE_LOG2W"): monkeypatch.delenv(k, raising=False)
+        for k, v in env.items(): monkeypatch.setenv(k, v)
+        c2 = vv.Context(0)
+        try:
+            c2.load_volume(vol, tf)
+            for (ci, kwt), (frame, n) in want.items():
+                got = c2.render(333, 211, cams[ci], fill=3, options=vv.make_options(count_samples=True, **dict(kwt)))
+                assert_frames_close(got, frame, f"{env} camera {ci} {kwt}")
+                assert c2.last_sample_count() == n, (env, ci, kwt)
+        finally:
+            c2.close()

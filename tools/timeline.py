@@ -12,10 +12,11 @@ import bench
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--orbit", default=""); ap.add_argument("--frames", type=int, default=3); ap.add_argument("--size", type=int, default=1024)
+ap.add_argument("--w", type=int, default=1920); ap.add_argument("--h", type=int, default=1080); ap.add_argument("--steps", type=int, default=512)
 ap.add_argument("--volume", default="noise"); ap.add_argument("--tf", default="ramp"); ap.add_argument("--out", default="gpurun_out/timeline.npz")
 a = ap.parse_args()
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
-n, W, H, steps = a.size, 1920, 1080, 512
+n, W, H, steps = a.size, a.w, a.h, a.steps
 ctx = vv.Context(0)
 ts = torch.cuda.Stream(device=dev); torch.cuda.set_stream(ts); stream = vv.stream_handle(ts)
 v8 = torch.empty(n ** 3, dtype=torch.uint8, device=dev)
@@ -50,7 +51,7 @@ T = T[used]; idx = np.nonzero(used)[0]
 t0, t1 = T[:, 0].astype(np.float64), T[:, 1].astype(np.float64)
 base = t0.min(); t0 = (t0 - base) / 100.0; t1 = (t1 - base) / 100.0        # us (100 MHz)
 strip, tile = (T[:, 2] >> 16).astype(int), (T[:, 2] & 0xffff).astype(int)
-xcc, live = (T[:, 3] & 15).astype(int), (T[:, 3] >> 8) & 1
+xcc, live, hwid = (T[:, 3] & 15).astype(int), (T[:, 3] >> 8) & 1, (T[:, 3] >> 16).astype(np.int64)
 dur = t1 - t0
 end = t1.max()
 print(f"blocks {len(T)}  frame span {end:.1f} us   xcc == blockIdx % 8 for {np.mean(xcc == (idx & 7)) * 100:.1f} % of the blocks")
@@ -84,4 +85,4 @@ print(f"start gap between x-neighbours (marching): median {np.median(gaps):.1f} 
 per_xcd_end = [t1[(xcc == k)].max() for k in range(8)]
 print("last block end per XCD (us):", " ".join(f"{v:.0f}" for v in per_xcd_end))
 os.makedirs(os.path.dirname(a.out), exist_ok=True)
-np.savez_compressed(a.out, t0=t0, t1=t1, strip=strip, tile=tile, xcc=xcc, live=live, idx=idx)
+np.savez_compressed(a.out, t0=t0, t1=t1, strip=strip, tile=tile, xcc=xcc, live=live, idx=idx, hwid=hwid)

@@ -11,7 +11,11 @@ struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips,
                   int blk_log2w;      // a block covers 2^blk_log2w x (256 >> blk_log2w) pixels (5: 32 x 8; 32 x 2 tiles also 64 x 4 / 128 x 2, 8 x 8 tiles 16 x 16 / 8 x 32); strips are that high
                   // march_kernel launches the tiles of columns [tx0, tx0 + wr) of strips [s0, s1) only: the tiles under the volume's screen rectangle
                   // (vv_render: screen_rect) -- or all of them: tx0 = 0, wr = tile columns of the frame, s0 = 0, s1 = n_strips
-                  int tx0, wr, s0, s1; };
+                  int tx0, wr, s0, s1;
+                  // order != nullptr: block L marches the tile in slot ((j / order_run) * 8 + L % 8) * order_run + j % order_run, j = L / 8, of a table that
+                  // rad_kernel's extra block writes (see there): runs of order_run x-adjacent tiles, sorted by the time their rays spend in the cube and dealt
+                  // to the XCDs so that all of them carry the same load and end on their lightest runs (speed only).
+                  const uint32_t *order; int order_run, order_raster; };
 // the same rectangle in pixels: [x0, x1) x [y0, y1).  Every owned pixel outside it is a pixel whose ray misses the volume: rad_kernel writes its 0,
 // and computes no radius for slabs that do not meet the rectangle (march_kernel, which reads them, is not launched there).  No rectangle: x1 = y1 = INT_MAX.
 struct PixelRect { int x0, x1, y0, y1; };
@@ -33,6 +37,7 @@ struct MarchArgs {
     StripMap strips;                   // march_kernel: strips of 8 pixel rows (n_strips of them)
     PixelRect rect;                    // rad_kernel + march kernels: the pixels the march kernel's tiles / slabs cover
     bool fill_outside;                 // Phong frames: rad_kernel is launched (without radii) to write the pixels outside `rect`
+    uint32_t *order_out;               // rad_kernel: where its extra block writes StripMap::order (nullptr: no such block)
     SlabMap slabs;                     // march_phong_kernel grid.y = n_regular + 1
     const float4 *tf;           // device, 256 entries
     const float *rad;           // device, nbx*nby (read by march_kernel)

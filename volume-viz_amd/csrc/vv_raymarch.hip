@@ -113,8 +113,79 @@ __device__ __noinline__ void mark_sample_lines(const InstrArgs &I, const VolumeV
 // pixels per lane, minimum by wave shuffles -- no LDS, no block barrier.  The minimum of a set of
 // floats does not depend on the order fminf visits them in, so the value equals the reference's tree.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rad_kernel(FrameParams P, float *__restrict__ rad, PixelRect R, uint32_t *__restrict__ pixels)
+// How long the ray through pixel-grid point (gx, gy) -- tile corners of the launch (StripMap), gx in [0, wr], gy in [0, s1 - s0] -- stays inside the cube, as one
+// of 64 classes, longest = 0.  Speed only: the same slab test as ray_endpoints, nothing here reaches a pixel.  (Corners, not tile centres: along a silhouette
+// edge made by a face seen at a grazing angle the chord jumps from 0 to the face's length, and a tile whose centre misses the cube can hold the frame's longest rays.)
+__device__ __forceinline__ int point_life_class(const FrameParams &P, const StripMap &M, int gx, int gy)
 {
+    const int bl = M.blk_log2w, bh = 256 >> bl;
+    const int strip = M.s0 + gy, tile_x = M.tx0 + gx;
+    const float x = (float)(tile_x << bl) - 0.5f, y = (float)(M.y0 + (strip / M.strips_per_band) * M.band_stride_px + (strip % M.strips_per_band) * bh) - 0.5f;
+    const float sx = ((2.0f * (x + 0.5f)) / (float)P.W - 1.0f) * P.tan_half_x, sy = ((2.0f * (y + 0.5f)) / (float)P.H - 1.0f) * P.tan_half_y;
+    float tmin = 0.f, tmax = INFINITY, d2 = 0.f, s2 = 0.f;
+    bool miss = false;
+    for (int a = 0; a < 3; a++) {
+        const float d = P.side[a] * sx + P.up[a] * sy + P.look[a], o = P.cam_pos[a], sc = P.scale[a];
+        d2 += d * d; s2 += sc * sc;
+        if (d != 0.0f) { const float t1 = (-sc - o) / d, t2 = (sc - o) / d; tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2)); }
+        else if (o < -sc || o > sc) miss = true;
+    }
+    float len = (miss || !(tmin <= tmax)) ? 0.f : (tmax - tmin) * sqrtf(d2);
+    const float cls = len / (2.0f * sqrtf(s2)) * 64.f;                    // (the cube's diagonal = the longest chord)
+    const int k = cls >= 63.f ? 63 : (cls > 0.f ? (int)cls : 0);
+    return 63 - k;
+}
+
+constexpr int kMaxUnits = 1024, kMaxPoints = 24576;
+__global__ __launch_bounds__(256) void rad_kernel(FrameParams P, float *__restrict__ rad, PixelRect R, uint32_t *__restrict__ pixels,
+                                                  StripMap M, uint32_t *__restrict__ order)
+{
+    if (order && blockIdx.x == gridDim.x - 1) {
+        // The extra block: StripMap::order.  Units = runs of order_run x-adjacent tiles of a strip (the tiles that share cache lines stay together, on one
+        // XCD); a unit weighs what its tiles' centre rays spend inside the cube.  Units sorted by weight (heaviest first; rank sort, ties in raster order)
+        // are dealt to the XCDs to and fro (0..7, 7..0, ...): every XCD gets the same load to within one light unit and ends on its lightest ones.
+        // Table slot ((r * 8 + xcd) * run + i) holds tile i of the r-th unit of that XCD, or ~0 (a unit shorter than a run, the last round).
+        __shared__ uint32_t w[kMaxUnits];
+        __shared__ uint8_t pts[kMaxPoints];
+        const int run = M.order_run, nseg = (M.wr + run - 1) / run, ns = M.s1 - M.s0, U = ns * nseg, n = M.wr * ns;
+        const int rounds = (U + 7) / 8;
+        for (int i = threadIdx.x; i < U; i += 256) w[i] = 0;
+        for (int i = threadIdx.x; i < rounds * 8 * run; i += 256) order[i] = ~0u;
+        __syncthreads();
+        {
+            // a tile weighs what the longest of its four corner rays spends in the cube
+            const int gw = M.wr + 1, np = gw * (ns + 1);
+            for (int i = threadIdx.x; i < np; i += 256) pts[i] = (uint8_t)point_life_class(P, M, i % gw, i / gw);
+            __syncthreads();
+            for (int t = threadIdx.x; t < n; t += 256) {
+                const int tx = t % M.wr, ty = t / M.wr;
+                const int c = min(min((int)pts[ty * gw + tx], (int)pts[ty * gw + tx + 1]), min((int)pts[(ty + 1) * gw + tx], (int)pts[(ty + 1) * gw + tx + 1]));
+                atomicAdd(&w[ty * nseg + tx / run], 64u - (uint32_t)c);
+            }
+        }
+        __syncthreads();
+        __shared__ uint16_t rk[kMaxUnits];
+        for (int u = threadIdx.x; u < U; u += 256) {
+            const uint32_t wu = w[u];
+            int rank = 0;
+            for (int v = 0; v < U; ++v) { const uint32_t wv = w[v]; rank += (wv > wu || (wv == wu && v < u)) ? 1 : 0; }
+            rk[u] = (uint16_t)rank;
+        }
+        __syncthreads();
+        for (int u = threadIdx.x; u < U; u += 256) {
+            const int rank = rk[u], c = rank & 7;
+            int r = rank >> 3;
+            const int xcd = (r & 1) ? 7 - c : c;
+            if (M.order_raster) {                                         // each XCD takes its units in raster order instead of heaviest first
+                r = 0;
+                for (int v = 0; v < u; ++v) { const int rv = rk[v], cv = rv & 7; r += (((rv >> 3) & 1) ? 7 - cv : cv) == xcd ? 1 : 0; }
+            }
+            const int strip_l = u / nseg, x0 = (u % nseg) * run, size = min(run, M.wr - x0);
+            uint32_t *dst = order + (size_t)(r * 8 + xcd) * run;
+            for (int i = 0; i < size; ++i) dst[i] = (uint32_t)(strip_l * M.wr + x0 + i);
+        }
+        return;
+    }
     const int slab = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (slab >= P.nbx * P.nby) return;                                     // wave-uniform
     const int bx = slab % P.nbx, by = slab / P.nbx;
@@ -193,7 +264,13 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bl = M.blk_log2w, ntx = M.wr;                               // block = 2^bl x (256 >> bl) pixels; the launch covers ntx tile columns from M.tx0 on
     int strip, tile_x;
-    if (M.xcd_band > 0) {
+    if (M.order) {
+        // runs of order_run consecutive tiles of the list go to one XCD (block L runs on XCD L % 8): x-neighbours share an L2 as in the strip order below
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3, pos = ((j / M.order_run) * 8 + xcd) * M.order_run + j % M.order_run;
+        const uint32_t t = M.order[pos];                              // (the grid is exactly the table)
+        if (t == ~0u) return;                                         // block-uniform, before any barrier
+        strip = M.s0 + (int)t / ntx; tile_x = M.tx0 + (int)t % ntx;
+    } else if (M.xcd_band > 0) {
         // XCD-aware order (speed only): linear block L runs on XCD L % 8 (round-robin dispatch);
         // XCD k walks bands k, k+8, ... of xcd_band strips so that neighbouring tiles share an L2
         const int L = blockIdx.x, per_band = ntx * M.xcd_band;
@@ -416,7 +493,7 @@ __global__ __launch_bounds__(256) void march_kernel(FrameParams P, VolumeView V,
         if (I.timeline && threadIdx.x == 0) {
             unsigned long long *t = I.timeline + 4ull * blockIdx.x;
             t[0] = tl0; t[1] = wall_clock64(); t[2] = ((unsigned long long)strip << 16) | (unsigned)tile_x;
-            t[3] = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) | (any_live ? 256u : 0u);      // HW_REG_XCC_ID
+            t[3] = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) | (any_live ? 256u : 0u) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16);      // HW_REG_XCC_ID, HW_REG_HW_ID
         }
     }
 #endif
@@ -737,7 +814,10 @@ static void launch_march(const MarchArgs &a, hipStream_t s)
     const int ntx = a.strips.wr, ns = a.strips.s1 - a.strips.s0;          // the tiles under the volume's screen rectangle (StripMap)
     if (ntx <= 0 || ns <= 0) return;
     unsigned nblocks = (unsigned)(ns * ntx);
-    if (a.strips.xcd_band > 0) {
+    if (a.strips.order) {
+        const int nseg = (ntx + a.strips.order_run - 1) / a.strips.order_run, units = ns * nseg;
+        nblocks = (unsigned)((units + 7) / 8 * 8 * a.strips.order_run);          // (rad_kernel's table: rounds of 8 units)
+    } else if (a.strips.xcd_band > 0) {
         const int nbands = (ns + a.strips.xcd_band - 1) / a.strips.xcd_band;
         nblocks = (unsigned)(((nbands + 7) / 8) * 8 * a.strips.xcd_band * ntx);
     }
@@ -783,8 +863,8 @@ static void dispatch2(const MarchArgs &a, hipStream_t s)
 static void launch_rad_impl(const MarchArgs &a, hipStream_t s)
 {
     // one wave per slab of the frame; waves of slab rows this shard does not own exit at once
-    dim3 grid((unsigned)((a.P.nbx * a.P.nby + 3) / 4));
-    hipLaunchKernelGGL(rad_kernel, grid, dim3(256), 0, s, a.P, a.rad_out, a.rect, a.pixels);
+    dim3 grid((unsigned)((a.P.nbx * a.P.nby + 3) / 4) + (a.order_out ? 1u : 0u));        // (+ the block that sorts the tiles: StripMap::order)
+    hipLaunchKernelGGL(rad_kernel, grid, dim3(256), 0, s, a.P, a.rad_out, a.rect, a.pixels, a.strips, a.order_out);
 }
 
 static void launch_raymarch_impl(const MarchArgs &a, hipStream_t s)
