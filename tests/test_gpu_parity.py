@@ -1493,7 +1493,7 @@ def test_tile_order_table(ctx, monkeypatch):
             key = (ci, tuple(sorted(kw.items())))
             want[key] = O.render(vol, tf, 333, 211, cam, fill=3, options=vv.make_options(count_samples=True, **kw))
     for env in ({"VV_LPT": "1"}, {"VV_LPT": "1", "VV_LPT_RUN": "1"}, {"VV_LPT": "1", "VV_LPT_RUN": "5"}, {"VV_LPT": "1", "VV_LPT_RUN": "64"},
-                {"VV_LPT": "3"}, {"VV_LPT": "1", "VV_BRICKED": "0"}, {"VV_LPT": "1", "VV_BLOCK_W": "128", "VV_TILE_LOG2W": "5"}):
+                {"VV_LPT": "1", "VV_BRICKED": "0"}, {"VV_LPT": "1", "VV_BLOCK_W": "128", "VV_TILE_LOG2W": "5"}):
         for k in ("VV_LPT", "VV_LPT_RUN", "VV_BRICKED", "VV_BLOCK_W", "VV_TILE_LOG2W"): monkeypatch.delenv(k, raising=False)
         for k, v in env.items(): monkeypatch.setenv(k, v)
         c2 = vv.Context(0)

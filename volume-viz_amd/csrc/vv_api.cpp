@@ -1146,7 +1146,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
     if (rc) return rc;
     // Balanced, heaviest-first tile order (StripMap::order, built by rad_kernel's extra block): analytic rays (the weights are the centre rays' chords),
     // 8 ... 1024 units of at most 16 x-adjacent tiles.  VV_LPT=0 switches it off, VV_LPT_RUN sets the unit length.
-    A.strips.order = nullptr; A.order_out = nullptr; A.strips.order_run = 1; A.strips.order_raster = 0;
+    A.strips.order = nullptr; A.order_out = nullptr; A.strips.order_run = 1;
     {
         const int wr = A.strips.wr, ns = A.strips.s1 - A.strips.s0;
         int run = wr > 0 ? (wr + (wr + 15) / 16 - 1) / ((wr + 15) / 16) : 1;                  // the strip in ceil(wr / 16) equal runs
@@ -1159,7 +1159,7 @@ int vv_render(vv_context *c, int W, int H, const slice_params *slice, const came
             const size_t words = (size_t)((units + 7) / 8 * 8) * run;
             rc = ensure(c, (void **)&c->d_order, &c->order_cap, std::max(words, (size_t)65536) * sizeof(uint32_t));
             if (rc) return rc;
-            A.strips.order = c->d_order; A.order_out = c->d_order; A.strips.order_run = run; A.strips.order_raster = c->knobs.lpt == 3;
+            A.strips.order = c->d_order; A.order_out = c->d_order; A.strips.order_run = run;
         }
     }
     A.rad = c->d_rad; A.rad_out = c->d_rad;

@@ -15,7 +15,7 @@ struct StripMap { int y0, strips_per_band, band_stride_px, tile_log2w, n_strips,
                   // order != nullptr: block L marches the tile in slot ((j / order_run) * 8 + L % 8) * order_run + j % order_run, j = L / 8, of a table that
                   // rad_kernel's extra block writes (see there): runs of order_run x-adjacent tiles, sorted by the time their rays spend in the cube and dealt
                   // to the XCDs so that all of them carry the same load and end on their lightest runs (speed only).
-                  const uint32_t *order; int order_run, order_raster; };
+                  const uint32_t *order; int order_run; };
 // the same rectangle in pixels: [x0, x1) x [y0, y1).  Every owned pixel outside it is a pixel whose ray misses the volume: rad_kernel writes its 0,
 // and computes no radius for slabs that do not meet the rectangle (march_kernel, which reads them, is not launched there).  No rectangle: x1 = y1 = INT_MAX.
 struct PixelRect { int x0, x1, y0, y1; };

@@ -164,22 +164,11 @@ __global__ __launch_bounds__(256) void rad_kernel(FrameParams P, float *__restri
             }
         }
         __syncthreads();
-        __shared__ uint16_t rk[kMaxUnits];
         for (int u = threadIdx.x; u < U; u += 256) {
             const uint32_t wu = w[u];
             int rank = 0;
             for (int v = 0; v < U; ++v) { const uint32_t wv = w[v]; rank += (wv > wu || (wv == wu && v < u)) ? 1 : 0; }
-            rk[u] = (uint16_t)rank;
-        }
-        __syncthreads();
-        for (int u = threadIdx.x; u < U; u += 256) {
-            const int rank = rk[u], c = rank & 7;
-            int r = rank >> 3;
-            const int xcd = (r & 1) ? 7 - c : c;
-            if (M.order_raster) {                                         // each XCD takes its units in raster order instead of heaviest first
-                r = 0;
-                for (int v = 0; v < u; ++v) { const int rv = rk[v], cv = rv & 7; r += (((rv >> 3) & 1) ? 7 - cv : cv) == xcd ? 1 : 0; }
-            }
+            const int c = rank & 7, r = rank >> 3, xcd = (r & 1) ? 7 - c : c;
             const int strip_l = u / nseg, x0 = (u % nseg) * run, size = min(run, M.wr - x0);
             uint32_t *dst = order + (size_t)(r * 8 + xcd) * run;
             for (int i = 0; i < size; ++i) dst[i] = (uint32_t)(strip_l * M.wr + x0 + i);
