@@ -48,7 +48,7 @@ if has pmcphong; then
     i=$((i+1))
     VV_BENCH_NO_EXTRA=1 rocprofv3 --pmc $pass --output-format csv -d $OUT/phong/pmc_$i -o pmc -- python3 bench.py --phong --steps 20 --warmup 5 --no-cpu-baseline > $OUT/phong/pmc_$i.json 2> $OUT/phong/pmc_$i.err || echo "phong pmc pass $i failed"
   done
-  python3 tools/pmc_summary.py $OUT/phong "big::march_phong_kernel<-1, 1, true, false>" > $OUT/pmc_march_phong_kernel.txt
+  python3 tools/pmc_summary.py $OUT/phong "march_phong_kernel<-1, 1, true, false>" > $OUT/pmc_march_phong_kernel.txt
 fi
 if has sub; then python3 tools/pmc_sub.py > $OUT/pmc_sub.log 2>&1 || echo "pmc_sub failed"; cp gpurun_out/pmc_sub.json $OUT/ 2>/dev/null; fi
 if has traffic; then python3 tools/pmc_traffic.py > $OUT/pmc_traffic.log 2>&1 || echo "pmc_traffic failed"; cp gpurun_out/pmc_traffic.json $OUT/ 2>/dev/null; fi

@@ -24,7 +24,7 @@ using namespace vv;
 struct vv_knobs {
     int tile_log2w = -1, xcd_band = -1, unroll = -1, lds_reserve = -1, lds_reserve_phong = -1;
     int bricked = -1, zpair = -1, zfast = -1, force_big = 0;
-    int block_w = -1, tail = -1, rect = -1, lpt = -1, lpt_run = -1;
+    int block_w = -1, tail = -1, rect = -1, lpt = -1, lpt_run = -1, phong_bricks = -1;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     void read()
     {
@@ -33,7 +33,7 @@ struct vv_knobs {
         bricked = geti("VV_BRICKED", -1); zpair = geti("VV_ZPAIR", -1);
         block_w = geti("VV_BLOCK_W", -1); tail = geti("VV_TAIL", -1);
         zfast = geti("VV_ZFAST", -1); force_big = getenv("VV_FORCE_BIG") != nullptr;
-        rect = geti("VV_RECT", -1); lpt = geti("VV_LPT", -1); lpt_run = geti("VV_LPT_RUN", -1);
+        rect = geti("VV_RECT", -1); lpt = geti("VV_LPT", -1); lpt_run = geti("VV_LPT_RUN", -1); phong_bricks = geti("VV_PHONG_BRICKS", -1);
     }
 };
 
@@ -790,6 +790,18 @@ static bool choose_launch(vv_context *c, MarchArgs &A, const camera_params *cam,
         if (ax >= 0.97f * sqrtf(ax * ax + ay * ay + az * az)) A.strips.tile_log2w = 5;
     }
     const vv_knobs &K = c->knobs;
+    // Sampling density: voxels of volume per sample = (voxels per step) x (voxels per pixel)^2 at the
+    // cube centre.  Sparse rays (C3 at 1080p: 4.9) reuse little of a cache line and want few waves on a CU's
+    // L1; the denser frames of the multi-GPU configurations (2716x1528: 2.5, 3840x2160: 1.2, and 0.6 at
+    // step 1/1024) want more: the whole 3840x2160 / 1024-step frame takes 3.51 ms with 2 blocks per CU and
+    // 2.71 ms with 4 (tools/sweep.sh --frame-of 8; bricked copy 4.71 -> 3.34 ms, Phong 9.0 -> 7.9 ms).
+    if ((rays->mode == VV_RAYS_ANALYTIC || image_source_has_hint(rays)) && have_basis && H > 0) {
+        const float dist = vlen_h(cam->origin[0], cam->origin[1], cam->origin[2]);
+        const float vpw = cbrtf(((float)c->nx / (2.f * P.scale[0])) * ((float)c->ny / (2.f * P.scale[1])) * ((float)c->nz / (2.f * P.scale[2])));
+        const float px_vox = 2.f * P.tan_half_y * dist / (float)H * vpw;
+        const float step_vox = fmaxf(P.step[0] * c->nx, fmaxf(P.step[1] * c->ny, P.step[2] * c->nz));
+        if (std::isfinite(px_vox) && std::isfinite(step_vox) && px_vox > 0.f && step_vox > 0.f) density = step_vox * px_vox * px_vox;
+    }
     // z-fastest copy (speed only): when the screen x direction maps onto the volume's z axis (side views) the same 32 x 2 tile reads whole
     // lines of a copy whose rows run along z -- the front view's kernel instead of the bricked copy's (C3 1.33 -> 1.0 ms, C2 0.223 -> 0.186,
     // profiles/r04_side_view.txt).  Both voxel types, both kernels, every volume the bricked copy would serve; built on first use if HBM has
@@ -800,6 +812,15 @@ static bool choose_launch(vv_context *c, MarchArgs &A, const camera_params *cam,
         use_zfast = az >= 0.97f * sqrtf(ax * ax + ay * ay + az * az) && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
         if (K.zfast >= 0) use_zfast = K.zfast != 0;
     }
+    // Phong frames of f32 volumes beyond the caches sample the bricked copy from every direction: march_phong_kernel's blocks are 16 pixels wide whatever the
+    // view, and 16 pixels of a row use 0.8 of the 1.8 lines they touch in a linear layout, while a 4 x 4 x 4 brick is used whole.  Measured:
+    // C3 + Phong along z 1.750 -> 1.650 ms (-5.5 %), from the side (z-fastest copy) 1.758 -> 1.666; volumes in the caches lose 20 % (VALU-bound): not for those.
+    // The 32 GiB volume of C5 (a pixel every 3.2 voxels: a brick serves 1.5 pixels a side) loses 9 %, the dense frame of the 8-GPU configuration 15 %, 768^3
+    // (1.8 GiB, 2.2 voxels per sample) 12 %: for sparse frames (3.5 ... 8 voxels per sample) of volumes between 2 and 8 GiB.  VV_PHONG_BRICKS=0/1 overrides.
+    const bool phong_bricks_fit = K.phong_bricks > 0 || (density > 3.5f && density <= 8.f && c->vol_bytes > (2ull << 30) && c->vol_bytes <= (8ull << 30));
+    const bool phong_bricks = phong_bricks_fit && shading->phongShading && c->vol_bytes > (1ull << 30) && c->vtype == VV_VOXEL_F32 && K.bricked != 0 && K.phong_bricks != 0 &&
+                              (c->bricks_valid || (c->build_in_render && !c->bricks_failed));
+    if (phong_bricks && K.zfast < 0) use_zfast = false;
     ++c->frame_no;
     const unsigned long long builds_before = (unsigned long long)c->bricks_valid + c->zpair_valid + c->zfast_valid + c->xpair_valid;
     if (use_zfast) use_zfast = c->build_in_render ? ensure_zfast(c, st) : c->zfast_valid;
@@ -820,18 +841,6 @@ static bool choose_launch(vv_context *c, MarchArgs &A, const camera_params *cam,
     A.strips.xcd_band = 1;
     if (K.xcd_band >= 0 && K.xcd_band <= 64) A.strips.xcd_band = K.xcd_band;
     const bool beyond_caches = c->vol_bytes > (1ull << 30);
-    // Sampling density: voxels of volume per sample = (voxels per step) x (voxels per pixel)^2 at the
-    // cube centre.  Sparse rays (C3 at 1080p: 4.9) reuse little of a cache line and want few waves on a CU's
-    // L1; the denser frames of the multi-GPU configurations (2716x1528: 2.5, 3840x2160: 1.2, and 0.6 at
-    // step 1/1024) want more: the whole 3840x2160 / 1024-step frame takes 3.51 ms with 2 blocks per CU and
-    // 2.71 ms with 4 (tools/sweep.sh --frame-of 8; bricked copy 4.71 -> 3.34 ms, Phong 9.0 -> 7.9 ms).
-    if ((rays->mode == VV_RAYS_ANALYTIC || image_source_has_hint(rays)) && have_basis && H > 0) {
-        const float dist = vlen_h(cam->origin[0], cam->origin[1], cam->origin[2]);
-        const float vpw = cbrtf(((float)c->nx / (2.f * P.scale[0])) * ((float)c->ny / (2.f * P.scale[1])) * ((float)c->nz / (2.f * P.scale[2])));
-        const float px_vox = 2.f * P.tan_half_y * dist / (float)H * vpw;
-        const float step_vox = fmaxf(P.step[0] * c->nx, fmaxf(P.step[1] * c->ny, P.step[2] * c->nz));
-        if (std::isfinite(px_vox) && std::isfinite(step_vox) && px_vox > 0.f && step_vox > 0.f) density = step_vox * px_vox * px_vox;
-    }
     const int big_reserve = density > 3.5f ? 76000 : (density > 1.8f ? 49000 : 36000);   // 2 / 3 / 4 blocks per CU
     // 3 samples per trip along the memory axis (A/B with repeats on MI355X: C3 -1.6 %, C2 -5.7 %, 512^3 -10 %,
     // u8 1024^3 -6.5 %; 4 per trip is no better), 2 on the bricked copy (3 there: +3.5 %)
@@ -869,7 +878,7 @@ static bool choose_launch(vv_context *c, MarchArgs &A, const camera_params *cam,
     // built on first use if HBM has room (1.25x an f32 volume, 2x a u8 volume).  VV_BRICKED=0/1 overrides the policy.
     // Measured: 1024^3 rotated 3.85 -> 1.65 ms (f32), 3.17 -> 0.99 ms (u8); C2 (256^3) -19 %, C1 (128^3) -9 %;
     // only volumes far below the frame's sampling density lose (64^3 at 1080p, step 1/512: +10 %).
-    bool use_bricks = A.strips.tile_log2w == 3 && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
+    bool use_bricks = (A.strips.tile_log2w == 3 || phong_bricks) && (size_t)c->nx * c->ny * c->nz >= (1ull << 21);
     if (K.bricked >= 0) use_bricks = K.bricked != 0;
     if (use_zfast) use_bricks = false;
     if (use_bricks) use_bricks = c->build_in_render ? ensure_bricks(c, st) : c->bricks_valid;
