@@ -11,7 +11,7 @@ import volviz_amd as vv
 import bench
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--orbit", default=""); ap.add_argument("--frames", type=int, default=3); ap.add_argument("--size", type=int, default=1024)
+ap.add_argument("--orbit", default=""); ap.add_argument("--phong", action="store_true"); ap.add_argument("--frames", type=int, default=3); ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--w", type=int, default=1920); ap.add_argument("--h", type=int, default=1080); ap.add_argument("--steps", type=int, default=512)
 ap.add_argument("--volume", default="noise"); ap.add_argument("--tf", default="ramp"); ap.add_argument("--out", default="gpurun_out/timeline.npz")
 a = ap.parse_args()
@@ -32,7 +32,7 @@ if a.orbit:
     th, ph = (float(v) for v in a.orbit.split(",")); cam = vv.Camera.orbit(4.0, np.radians(th), np.radians(ph))
 opts = vv.make_options(step=1.0 / steps)
 frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
-for _ in range(50): ctx.render_device(W, H, cam, frame.data_ptr(), options=opts, stream=stream)
+for _ in range(50): ctx.render_device(W, H, cam, frame.data_ptr(), options=opts, stream=stream, phong=a.phong)
 torch.cuda.synchronize()
 NB = 1 << 16
 tl = torch.zeros(NB * 4, dtype=torch.int64, device=dev)
@@ -40,7 +40,7 @@ os.environ["VV_TIMELINE_PTR"] = str(tl.data_ptr())
 res = []
 for f in range(a.frames):
     tl.zero_(); torch.cuda.synchronize()
-    ctx.render_device(W, H, cam, frame.data_ptr(), options=opts, stream=stream)
+    ctx.render_device(W, H, cam, frame.data_ptr(), options=opts, stream=stream, phong=a.phong)
     torch.cuda.synchronize()
     res.append(tl.cpu().numpy().reshape(NB, 4).copy())
 del os.environ["VV_TIMELINE_PTR"]

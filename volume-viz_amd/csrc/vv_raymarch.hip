@@ -552,6 +552,9 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
     __shared__ float q255[256];              // q / 255.f for every byte q, by the same IEEE division
     __shared__ int any_live[2];              // refresh depth of the chunk of iteration `it`: any_live[it & 1]
     const int tid = threadIdx.x;
+#ifdef VV_TIMELINE
+    const unsigned long long tl0 = wall_clock64();
+#endif
     // XCD-aware order (speed only, as in march_kernel): linear block L runs on XCD L % 8; XCD k takes the
     // grid rows k, k+8, ... so that the slabs of one row, which share volume lines, share an L2
     const int nbxg = M.wg;                   // (slab columns the launch covers, from M.gx0 on)
@@ -786,6 +789,13 @@ __global__ __launch_bounds__(256) VV_PHONG_OCC void march_phong_kernel(FramePara
 
     if (writer)
         pixels[(size_t)y * P.W + x] = skip ? 0u : pack_rgba(res_r, res_g, res_b, res_a);
+#ifdef VV_TIMELINE
+    if (I.timeline && threadIdx.x == 0) {
+        unsigned long long *t = I.timeline + 4ull * blockIdx.x;
+        t[0] = tl0; t[1] = wall_clock64(); t[2] = ((unsigned long long)by << 16) | (unsigned)bx;
+        t[3] = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) | 256u | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16);
+    }
+#endif
     if (INSTR) {
         for (int o = 32; o > 0; o >>= 1) executed += __shfl_down(executed, o);
         if ((threadIdx.x & 63) == 0 && executed) atomicAdd(counter, executed);
