@@ -9,10 +9,11 @@ import torch  # noqa: F401  (its HIP runtime first)
 import oracle_lib as O
 import volviz_amd as vv
 
-KNOBS = ("VV_ZFAST", "VV_BRICKED", "VV_ZPAIR", "VV_FORCE_BIG", "VV_PITCH_FORCE", "VV_UNROLL", "VV_BLOCK_W", "VV_TILE_LOG2W", "VV_TAIL")
+KNOBS = ("VV_ZFAST", "VV_BRICKED", "VV_ZPAIR", "VV_FORCE_BIG", "VV_PITCH_FORCE", "VV_UNROLL", "VV_BLOCK_W", "VV_TILE_LOG2W", "VV_TAIL", "VV_LPT", "VV_LPT_RUN", "VV_RECT", "VV_PHONG_BRICKS")
 ENVS = [{}, {"VV_ZFAST": "1"}, {"VV_BRICKED": "1"}, {"VV_ZPAIR": "1"}, {"VV_FORCE_BIG": "1"}, {"VV_PITCH_FORCE": "1"}, {"VV_UNROLL": "2"}, {"VV_UNROLL": "3", "VV_BRICKED": "1"},
         {"VV_ZFAST": "1", "VV_ZPAIR": "0"}, {"VV_UNROLL": "2", "VV_FORCE_BIG": "1"}, {"VV_BRICKED": "0"}, {"VV_FORCE_BIG": "1", "VV_BRICKED": "1"},
-        {"VV_BLOCK_W": "64", "VV_TILE_LOG2W": "5"}, {"VV_BLOCK_W": "128", "VV_TILE_LOG2W": "5"}, {"VV_BLOCK_W": "8", "VV_TILE_LOG2W": "3", "VV_BRICKED": "1"}, {"VV_TILE_LOG2W": "4"}, {"VV_TAIL": "0"}, {"VV_BLOCK_W": "16", "VV_TILE_LOG2W": "3"}]
+        {"VV_BLOCK_W": "64", "VV_TILE_LOG2W": "5"}, {"VV_BLOCK_W": "128", "VV_TILE_LOG2W": "5"}, {"VV_BLOCK_W": "8", "VV_TILE_LOG2W": "3", "VV_BRICKED": "1"}, {"VV_TILE_LOG2W": "4"}, {"VV_TAIL": "0"}, {"VV_BLOCK_W": "16", "VV_TILE_LOG2W": "3"},
+        {"VV_LPT": "1"}, {"VV_LPT": "1", "VV_LPT_RUN": "3", "VV_BRICKED": "1"}, {"VV_RECT": "0"}, {"VV_PHONG_BRICKS": "1"}, {"VV_LPT": "1", "VV_ZFAST": "1"}]
 
 
 def case(seed):
