@@ -359,6 +359,10 @@ unsigned long long vv_last_sample_count(vv_context *ctx);        /* executed sam
 int                vv_debug_last_launch(vv_context *ctx, int out[8]);  /* what the launch policy chose for the last vv_render (developer aid): wave tile log2 width,
                                                                        * block log2 width, samples per trip, LDS reserve, layout (0 linear, 1 linear/64-bit, 2 bricked,
                                                                        * 3 z-pair, 4 z-fastest, 5 x-pair), view known to the policy (0 / 1), density x 1000, Phong (0 / 1) */
+/* The rectangle of pixel coordinates (x_min, x_max, y_min, y_max, margin included) outside of which vv_render lets its pre-pass write (0,0,0,0) instead of
+ * marching (analytic ray sources): returns 1 and fills out[4], or 0 when this camera gets no rectangle (a cube corner at or behind the eye's plane, a
+ * margin wider than the frame).  Needs no device and no context: tests/test_host.py checks it against the oracle's ray-box test pixel by pixel. */
+int                vv_debug_screen_rect(int width, int height, const camera_params *cam, const vv_ray_source *rays, double out[4]);
 int                vv_debug_counters(vv_context *ctx, unsigned long long out[16]);  /* developer statistics of the last instrumented frame: [0] executed samples,
                                                                                      * [1] lane slots spent, [2] / [3] waves that sampled the bricked / a pair copy */
 /* The VV_* developer knobs of the environment are read when a context is created and at every volume load, never

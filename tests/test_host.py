@@ -283,3 +283,40 @@ def test_byte_over_255_without_a_division_is_the_ieee_quotient():
         assert q == want, b
         plain_wrong += q0 != want
     assert plain_wrong > 100                      # (the plain product b * fl(1 / 255) is off by an ulp for about half the bytes)
+
+
+def test_screen_rectangle_contains_every_hit_pixel():
+    """vv_render marches only under the volume's screen rectangle and writes (0,0,0,0) beside it (csrc/vv_api.cpp: screen_rect), so the rectangle must
+    contain every pixel whose ray meets the cube -- as the ORACLE's binary32 ray-box test sees it (analytic_endpoints, the arithmetic ray_endpoints restates).
+    Random and adversarial cameras (near, far, long and wide lenses, scaled cubes, eyes beside / above / inside the cube, odd frame sizes): every pixel the
+    oracle's first pass marks visible lies inside; where no rectangle is given the whole frame is marched, which needs no check.  Also: the rectangle is not
+    vacuous -- for the reference's default camera it is within 3 pixels of the hit pixels' bounding box."""
+    import oracle_lib as O
+    rng = np.random.default_rng(20251005)
+    cams = [vv.Camera(), vv.Camera(origin=(0, 0, -40.0), fov_y=4.0), vv.Camera(origin=(0, 0, -400.0), fov_y=0.4), vv.Camera(origin=(0.3, 0.2, -1.6), fov_y=100.0),
+            vv.Camera(origin=(0, 0, -1.0005)), vv.Camera(origin=(0.2, 0.1, 0.3)), vv.Camera(origin=(0, 0, -4.0), look_at=(2.4, 0, 0)),
+            vv.Camera(origin=(0, 0, -4.0), look_at=(9.0, 0, 0)), vv.Camera(origin=(1e4, 2e3, -3e4), fov_y=0.005), vv.Camera(origin=(0.0, 1.2, 0.0), up=(0, 0, 1), fov_y=150.0)]
+    for _ in range(260):
+        r = 10.0 ** rng.uniform(-0.3, 2.5)
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        scale = tuple(float(v) for v in 10.0 ** rng.uniform(-1.0, 0.6, 3)) if rng.random() < 0.5 else (1.0, 1.0, 1.0)
+        target = tuple(float(v) for v in rng.uniform(-1.5, 1.5, 3)) if rng.random() < 0.5 else (0.0, 0.0, 0.0)
+        up = (0.0, 1.0, 0.0) if rng.random() < 0.7 else tuple(float(v) for v in rng.normal(size=3))
+        cams.append(vv.Camera(origin=tuple(float(v) for v in d * r), look_at=target, up=up, fov_y=float(10.0 ** rng.uniform(-1.5, 2.1)), scale=scale))
+    n_rect = 0
+    for ci, cam in enumerate(cams):
+        W, H = [(97, 61), (64, 64), (131, 43), (29, 57)][ci % 4]
+        try:
+            rect = vv.screen_rect(cam, W, H)
+        except vv.VolvizError:
+            continue                                   # (up parallel to look: vv_render refuses the camera too)
+        if rect is None:
+            continue
+        n_rect += 1
+        front, back = O.first_pass(cam, W, H)
+        ys, xs = np.nonzero((front[..., 3] > 0) | (back[..., 3] > 0))
+        if len(xs):
+            assert xs.min() >= rect[0] and xs.max() <= rect[1] and ys.min() >= rect[2] and ys.max() <= rect[3], (ci, cam, rect, xs.min(), xs.max(), ys.min(), ys.max())
+        if ci == 0:
+            assert xs.min() - rect[0] <= 3 and rect[1] - xs.max() <= 3 and ys.min() - rect[2] <= 3 and rect[3] - ys.max() <= 3, rect
+    assert n_rect >= 100, n_rect

@@ -1265,6 +1265,18 @@ int vv_first_pass(vv_context *c, int W, int H, const camera_params *cam, const v
 
 // what vv_render chose for its last frame (developer aid, tests): {wave tile log2 width, block log2 width, samples per trip, LDS reserve,
 // layout (0 linear, 1 linear with 64-bit addressing, 2 bricked, 3 z-pair), 1 if the view was known to the policy, density x 1000, Phong}
+int vv_debug_screen_rect(int W, int H, const camera_params *cam, const vv_ray_source *rays, double out[4])
+{
+    if (!cam || !rays || !out || W < 1 || H < 1) return fail(nullptr, VV_ERR_INVALID, "vv_debug_screen_rect: bad argument");
+    if (rays->mode != VV_RAYS_ANALYTIC) return 0;
+    MarchArgs A;
+    memset(&A, 0, sizeof A);
+    for (int a = 0; a < 3; ++a) { A.P.cam_pos[a] = cam->origin[a]; A.P.scale[a] = cam->scale[a]; }
+    int rc = camera_basis(nullptr, A.P, cam, rays, W, H);
+    if (rc) return rc;
+    return screen_rect(A, W, H, &out[0], &out[1], &out[2], &out[3]) ? 1 : 0;
+}
+
 int vv_debug_last_launch(vv_context *c, int out[8])
 {
     if (!c || !out) return VV_ERR_INVALID;

@@ -82,7 +82,7 @@ EXPORTS = [
     "vv_camera_orbit_drag", "vv_camera_zoom", "vv_cut_plane_from_drag", "vv_cut_plane_drag",
     "vv_prepare_layouts", "vv_set_layout_policy", "vv_layout_state", "vv_device_bytes", "vv_reread_env",
     "vv_load_volume_stream_begin", "vv_load_volume_stream_slices", "vv_load_volume_stream_end", "vv_load_volume_t3d",
-    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset", "vv_debug_last_launch", "vv_set_frame_timing",
+    "vv_load_volume_stream_slices_async", "vv_load_volume_stream_wait_source", "vv_dataset_preset", "vv_debug_last_launch", "vv_set_frame_timing", "vv_debug_screen_rect",
 ]
 
 _lib = None
@@ -145,6 +145,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.vv_debug_counters.argtypes = [vp, vp]
     lib.vv_debug_last_launch.argtypes = [vp, vp]
     lib.vv_set_frame_timing.argtypes = [vp, i]
+    lib.vv_debug_screen_rect.argtypes = [i, i, C.POINTER(camera_params), C.POINTER(vv_ray_source), C.POINTER(C.c_double * 4)]
     lib.vv_reread_env.argtypes = [vp]
     lib.vv_prepare_layouts.argtypes = [vp, i, vp]
     lib.vv_device_bytes.argtypes = [vp, vp]
@@ -213,6 +214,16 @@ class Camera:
         """glwidget.cpp:435-445 orbit position."""
         return Camera(origin=(r * np.sin(theta) * np.cos(phi), r * np.cos(theta),
                               r * np.sin(theta) * np.sin(phi)), **kw)
+
+
+def screen_rect(cam: "Camera", width: int, height: int):
+    """vv_debug_screen_rect: (x_min, x_max, y_min, y_max) in pixel coordinates, or None when this camera gets no rectangle.  No device needed."""
+    out = (C.c_double * 4)()
+    cp = cam.params(width, height); rs = analytic_rays(cam)
+    rc = load_library().vv_debug_screen_rect(width, height, C.byref(cp), C.byref(rs), C.byref(out))
+    if rc < 0:
+        raise VolvizError(rc, "vv_debug_screen_rect")
+    return tuple(out) if rc == 1 else None
 
 
 def analytic_rays(cam: Camera, quantize8: bool = False, aspect: float = 0.0) -> vv_ray_source:
