@@ -362,7 +362,7 @@ int                vv_debug_last_launch(vv_context *ctx, int out[8]);  /* what t
 /* The rectangle of pixel coordinates (x_min, x_max, y_min, y_max, margin included) outside of which vv_render lets its pre-pass write (0,0,0,0) instead of
  * marching (analytic ray sources): returns 1 and fills out[4], or 0 when this camera gets no rectangle (a cube corner at or behind the eye's plane, a
  * margin wider than the frame).  Needs no device and no context: tests/test_host.py checks it against the oracle's ray-box test pixel by pixel. */
-int                vv_debug_screen_rect(int width, int height, const camera_params *cam, const vv_ray_source *rays, double out[4]);
+int                vv_debug_screen_rect(int width, int height, const struct camera_params *cam, const vv_ray_source *rays, double out[4]);
 int                vv_debug_counters(vv_context *ctx, unsigned long long out[16]);  /* developer statistics of the last instrumented frame: [0] executed samples,
                                                                                      * [1] lane slots spent, [2] / [3] waves that sampled the bricked / a pair copy */
 /* The VV_* developer knobs of the environment are read when a context is created and at every volume load, never
